@@ -1,0 +1,162 @@
+/* C ABI of libried_gan.so: the MI355X (gfx950) kernels under the RIED-GAN hot path.
+ *
+ * The reference (kevinmfreire/REID-GAN) is pure Python on torch.nn; it has no FFI of its own.
+ * Each entry point below therefore replaces the stock torch op(s) a reference line invokes; the
+ * citation names that line (paths relative to the reference repo).  A binding is a plain
+ * ctypes / cffi declaration of these prototypes.
+ *
+ * Conventions
+ *  - Every function returns 0 on success, non-zero on failure; ried_last_error() then holds a
+ *    message (thread local).  Arguments are validated before any launch.
+ *  - All pointers are device pointers owned by the caller unless named *_host.  The library never
+ *    allocates, frees or synchronises; every launch goes to the given stream, so calls may be
+ *    captured into a HIP graph.
+ *  - bf16 activations are NHWC.  A "view" (ptr, ld, C) addresses channels [0, C) of pixel p at
+ *    ptr + p*ld; C and ld are multiples of 8 and ptr is 16-byte aligned.  Views let a producer write
+ *    a channel slice of a concatenation buffer directly.
+ *  - fp32 images (the CT slices, the generator output, SSIM inputs) are [nimg][H][W].
+ */
+#ifndef RIED_GAN_H
+#define RIED_GAN_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ried_stream_t; /* == hipStream_t */
+
+const char* ried_last_error(void);
+int ried_abi_version(void);
+int ried_device_cus(void);
+
+/* ---- implicit-GEMM convolutions (bf16 in, fp32 accumulate, MFMA) -------------------------------
+ * Conv2d forward (transposed = 0): replaces nn.Conv2d at src/rinet.py:186 (BasicConv2d), :137 (SNConv2d),
+ * :100 (identity_downsample), :156-158 (attention projections), :265,360 (sample), and the VGG16 convs built
+ * at src/loss.py:74.
+ * transposed = 1: ConvTranspose2d forward (src/rinet.py:198) and the data gradient of a Conv2d.
+ *   x: view [nimg][H][W] with Cin channels; w: packed bf16 [Cout][kh][kw][Cin]; y: view [nimg][Ho][Wo], Cout.
+ *   bias: fp32 [Cout] or NULL; act: 0 none, 1 ReLU, 2 LeakyReLU(0.2); stats: fp32 [2][Cout] accumulated with the
+ *   per-channel sum and sum of squares of the fp32 results (for train-mode BatchNorm) or NULL;
+ *   accumulate: y += result; out_f32: y is fp32 instead of bf16. */
+int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W, int Cin,
+                int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
+                const float* bias, int act, float* stats, int accumulate, int out_f32, ried_stream_t stream);
+
+/* Weight-gradient partial sums (autograd of the convs above).  g is the tensor seen through the kernel window
+ * (Conv2d: the layer input; ConvTranspose2d: the output gradient), p the tensor indexed by output pixel.
+ * slab: fp32 [splitk][kh*kw][Cp][Cg].  Follow with ried_wgrad_reduce. */
+int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg, int H, int W, const void* p, long long ldp,
+                      int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw, float* slab, int splitk,
+                      ried_stream_t stream);
+/* out[tap*st + p*sp + g*sg] (+)= scale * sum over splits: scatters into the (Cout,Cin,kh,kw) or (Cin,Cout,kh,kw)
+ * fp32 master gradient. */
+int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp, int Cg, float* out, long long st, long long sp,
+                      long long sg, float scale, int accumulate, ried_stream_t stream);
+
+/* Batched out[b][n][m] = alpha * sum_k A[b][m][k] * B[b][n][k]; a_tr / b_tr: operand stored [k][row].
+ * Replaces torch.bmm at src/rinet.py:173,177 and their autograd.  gamma/resid: out = gamma[0]*value + resid. */
+int ried_bgemm(const void* A, long long lda, long long bsa, int a_tr, const void* B, long long ldb, long long bsb,
+               int b_tr, int M, int N, int K, int batch, void* out, long long ldc, long long bsc, int out_f32,
+               float alpha, const float* gamma, const void* resid, long long ld_resid, long long bs_resid,
+               int accumulate, ried_stream_t stream);
+
+/* fp32 master weight with element strides (sn, sr, ss, sc) -> bf16 [N][R][S][C], divided by sigma[0] if given
+ * (the W / sigma of spectral norm, torch/nn/utils/spectral_norm.py:113). */
+int ried_pack_weight(const float* src, void* dst, int N, int R, int S, int C, long long sn, long long sr, long long ss,
+                     long long sc, const float* sigma, ried_stream_t stream);
+
+/* ---- BatchNorm2d, train mode (src/rinet.py:187,199; eps 1e-5, momentum 0.1) ------------------------------------ */
+/* stats [2][C] (sum, sum sq over count values per channel) -> save [2][C] (mean, invstd); updates running stats
+ * (unbiased variance) and num_batches_tracked when given. */
+int ried_bn_finalize(const float* stats, int C, long long count, float eps, float momentum, float* save,
+                     float* running_mean, float* running_var, long long* num_batches_tracked, ried_stream_t stream);
+int ried_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* save,
+                       ried_stream_t stream);
+/* y = [relu](gamma*(x-mean)*invstd + beta) [+ y]   (the residual add of src/rinet.py:250,345,443 is the accumulate) */
+int ried_bn_apply(const void* x, long long ldx, void* y, long long ldy, long long npix, int C, const float* save,
+                  const float* gamma, const float* beta, int relu, int accumulate, ried_stream_t stream);
+/* dx = d(loss)/d(conv output) from dy = d(loss)/d(bn+relu output); sums: zeroed fp32 [2][C] scratch;
+ * dgamma/dbeta may be NULL. */
+int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
+                     long long npix, int C, const float* save, const float* gamma, const float* beta, int relu,
+                     float* sums, float* dgamma, float* dbeta, int accumulate, ried_stream_t stream);
+
+/* ---- pooling / upsampling ------------------------------------------------------------------------------------- */
+/* mode 0: MaxPool2d(3,2,1) (src/rinet.py:260,355); 1: MaxPool2d(2,2) (VGG16); 2: avg_pool2d(3,1,1) (:235,330,428) */
+int ried_pool_fwd(const void* x, long long ldx, void* y, long long ldy, int nimg, int H, int W, int C, int mode,
+                  ried_stream_t stream);
+int ried_pool_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int nimg,
+                  int H, int W, int C, int mode, ried_stream_t stream); /* dx += */
+/* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (src/rinet.py:266,361) */
+int ried_upsample2x_fwd(const void* x, long long ldx, void* y, long long ldy, int nimg, int H, int W, int C,
+                        ried_stream_t stream);
+int ried_upsample2x_bwd(const void* dy, long long lddy, void* dx, long long lddx, int nimg, int H, int W, int C,
+                        ried_stream_t stream); /* dx += */
+
+/* ---- elementwise / reductions --------------------------------------------------------------------------------- */
+/* op 0 copy, 1 out+=a, 2 out=a*act'(y), 3 out+=a*act'(y), 4 out=s[0]*a+y (src/rinet.py:180), 5 out=s[0]*a;
+ * act'(y) = y>0 ? 1 : slope, taken from the activation OUTPUT y (ReLU: slope 0; LeakyReLU: 0.2). */
+int ried_ew(int op, const void* a, long long lda, const void* y, long long ldy, void* out, long long ldo,
+            long long npix, int C, float slope, const float* s, ried_stream_t stream);
+int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, ried_stream_t stream); /* out[c] += */
+int ried_dot(const void* a, long long lda, const void* b, long long ldb, long long npix, int C, float scale, float* out,
+             ried_stream_t stream); /* out[0] += scale * sum a*b (b NULL: sum a) */
+int ried_fill(void* out, long long ldo, long long npix, int C, const float* s, float value, ried_stream_t stream);
+int ried_softmax_fwd(const float* S, void* P, long long rows, int n, ried_stream_t stream); /* src/rinet.py:174 */
+int ried_softmax_bwd(const float* dP, const void* P, void* dS, long long rows, int n, ried_stream_t stream);
+int ried_nchw_to_nhwc(const float* x, void* y, long long ldy, int nimg, int C, long long HW, ried_stream_t stream);
+int ried_nhwc_to_nchw(const void* x, long long ldx, float* y, int nimg, int C, long long HW, ried_stream_t stream);
+
+/* torch.optim.Adam step over a flat fp32 buffer (src/train.py:104-105,165,177); step >= 1 is the host's counter. */
+int ried_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
+              int step, ried_stream_t stream);
+
+/* ---- one-input-channel 3x3 pad-1 convolutions on the fp32 image ----------------------------------------------- */
+/* generator conv1 (src/rinet.py:55), discriminator layer 0 (:20), VGG16 layer 0 on cat([x,x,x]) (src/loss.py:181)
+ * with the three input planes folded.  w: fp32 [Cout][9]; sigma: NULL or the spectral norm to divide by;
+ * the input is used as x*in_scale + in_shift (normalize_, src/loss.py:20-22), zero padded after the affine. */
+int ried_conv_c1_fwd(const float* x, const float* w, const float* sigma, const float* bias, void* y, long long ldy,
+                     int nimg, int H, int W, int Cout, int stride, float in_scale, float in_shift, int act,
+                     float* stats, ried_stream_t stream);
+int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy, int nimg, int H, int W, int Cout, int stride,
+                       float in_scale, float in_shift, float* dw, ried_stream_t stream); /* dw[Cout][9] += */
+int ried_conv_c1_dgrad(const void* dy, long long lddy, const float* w, const float* sigma, float* dx, int nimg, int H,
+                       int W, int Cout, float scale, int accumulate, ried_stream_t stream); /* stride 1 */
+
+/* generator out_conv 33->1 on cat(identity, h) (src/rinet.py:70,90): out = w[0]*x + sum_c w[1+c]*h[:,c] */
+int ried_out_conv_fwd(const float* x, const void* h, long long ldh, const float* w, float* out, long long npix,
+                      ried_stream_t stream);
+int ried_out_conv_bwd(const float* x, const void* h, long long ldh, const float* w, const float* dout, void* dh,
+                      long long lddh, float* dw, long long npix, ried_stream_t stream); /* dw[33] += */
+
+/* ---- spectral norm (torch/nn/utils/spectral_norm.py:97-113 as used at src/rinet.py:138) ------------------------ */
+/* Wm: weight_orig as fp32 [R][K].  power_iter = 1 updates u [R] and v [K] in place, then sigma[0] = u.(W v).
+ * scratch: fp32 [K + R + 2]. */
+int ried_sn_sigma(const float* Wm, int R, int K, float* u, float* v, float* sigma, float* scratch, int power_iter,
+                  float eps, ried_stream_t stream);
+/* dW (+)= (dWsn - (sum(dWsn*W)/sigma) u v^T)/sigma ; scratch1: one fp32 */
+int ried_sn_backward(const float* dWsn, const float* Wm, const float* u, const float* v, const float* sigma, int R,
+                     int K, float* dW, float* scratch1, int accumulate, ried_stream_t stream);
+
+/* ---- losses ---------------------------------------------------------------------------------------------------- */
+/* nn.MSELoss on one VGG tap (src/loss.py:185-187): loss[0] += loss_scale*sum (a-b)^2; g (+)= grad_scale*(a-b) */
+int ried_mse_tap(const void* a, const void* b, long long n, float loss_scale, float* loss, void* g, float grad_scale,
+                 int accumulate, ried_stream_t stream);
+/* DLoss (src/loss.py:141-142): sc[0]=mean(pos), sc[1]=mean(neg) -> sc[2]=loss, sc[3], sc[4] = per-element gradients */
+int ried_dloss_scalars(float* sc, long long n_per_half, ried_stream_t stream);
+/* CompoundLoss weighting (src/loss.py:191-194): sc[1], sc[5]=vgg, sc[6]=ssim -> sc[7]=dssim, sc[8]=gen, sc[9]=loss */
+int ried_gloss_scalars(float* sc, float wv, float ws, float wg, ried_stream_t stream);
+
+/* ---- SSIM / metrics -------------------------------------------------------------------------------------------- */
+/* compute_SSIM (src/loss.py:42-67, src/measure.py:49-74) fused with compute_MSE (src/measure.py:18-19).
+ * sums[n][0] += sum ssim_map(a,ref), [1] += sum (a-ref)^2, and with b: [2], [3] the same for (b,ref).
+ * do_clamp folds trunc() of src/test.py:77-80.  gmap (two-image form): fp32 [3][nimg][H][W] for ried_ssim_bwd. */
+int ried_ssim_fwd(const float* a, const float* b, const float* ref, int nimg, int H, int W, float c1, float c2,
+                  int do_clamp, float lo, float hi, float* sums, float* gmap, ried_stream_t stream);
+/* da (+)= scale * scale_dev[0] * d(sum ssim_map)/d a */
+int ried_ssim_bwd(const float* a, const float* ref, const float* gmap, int nimg, int H, int W, float scale,
+                  const float* scale_dev, float* da, int accumulate, ried_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

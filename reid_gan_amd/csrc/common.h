@@ -1,0 +1,81 @@
+// Shared device/host helpers for the RIED-GAN gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef unsigned short bf16_t;                                   // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;     // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // one 16-byte chunk = 8 bf16
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define RIED_OK 0
+#define RIED_ERR_ARG 1
+#define RIED_ERR_HIP 2
+
+extern "C" const char* ried_last_error(void);
+void ried_set_error(const char* fmt, ...);
+
+#define RIED_CHECK_ARG(cond, ...)            \
+  do {                                       \
+    if (!(cond)) {                           \
+      ried_set_error(__VA_ARGS__);           \
+      return RIED_ERR_ARG;                   \
+    }                                        \
+  } while (0)
+
+#define RIED_CHECK_LAUNCH(name)                                            \
+  do {                                                                     \
+    hipError_t e_ = hipGetLastError();                                     \
+    if (e_ != hipSuccess) {                                                \
+      ried_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+      return RIED_ERR_HIP;                                                 \
+    }                                                                      \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;                                          // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+__device__ __forceinline__ float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// 64-lane wave reductions
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread
+__device__ __forceinline__ float block_sum_256(float v, float* sh4) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh4[w] = v;
+  __syncthreads();
+  return sh4[0] + sh4[1] + sh4[2] + sh4[3];
+}
+
+static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline int ew_grid(long long n, int per_block, int cap = 4096) {
+  long long g = (n + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
+  return (int)g;
+}

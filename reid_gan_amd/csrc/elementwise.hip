@@ -1,0 +1,805 @@
+// Bandwidth-bound kernels of the RIED-GAN hot path on NHWC bf16 activations:
+// batch-norm (train mode) apply/backward, pooling, bilinear upsampling,
+// activation backward, weight packing, softmax, bias/column sums, fused Adam.
+// Every kernel moves 16 bytes per lane (8 bf16 channels) and reduces with
+// 64-lane wavefront shuffles.
+//
+// A tensor "view" is (ptr, ld, C): pixel p's channels are ptr[p*ld .. p*ld+C).
+// Views let producers write straight into channel slices of a concatenation
+// buffer, which removes every torch.cat of src/rinet.py:88-90,245,291,340,387,418-438.
+#include "common.h"
+
+#define EW_THREADS 256
+
+__device__ __forceinline__ void unpack8(const u32x4& v, float (&f)[8]) {
+  f[0] = bflo(v[0]); f[1] = bfhi(v[0]); f[2] = bflo(v[1]); f[3] = bfhi(v[1]);
+  f[4] = bflo(v[2]); f[5] = bfhi(v[2]); f[6] = bflo(v[3]); f[7] = bfhi(v[3]);
+}
+__device__ __forceinline__ u32x4 pack8(const float (&f)[8]) {
+  return u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+}
+__device__ __forceinline__ u32x4 ld8(const bf16_t* p) { return *reinterpret_cast<const u32x4*>(p); }
+__device__ __forceinline__ void st8(bf16_t* p, const u32x4& v) { *reinterpret_cast<u32x4*>(p) = v; }
+
+static int check_view(const char* fn, const void* p, long long ld, int C) {
+  RIED_CHECK_ARG(p != nullptr, "%s: null pointer", fn);
+  RIED_CHECK_ARG(C > 0 && C % 8 == 0 && ld % 8 == 0 && ld >= C, "%s: C=%d ld=%lld must be multiples of 8, ld >= C", fn,
+                 C, ld);
+  RIED_CHECK_ARG(((uintptr_t)p % 16) == 0, "%s: pointer not 16-byte aligned", fn);
+  return RIED_OK;
+}
+#define CHECK_VIEW(fn, p, ld, C)                         \
+  do {                                                   \
+    int rc_ = check_view(fn, p, ld, C);                  \
+    if (rc_) return rc_;                                 \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// weight packing: fp32 master weight (any 4-d stride order) -> bf16 [N][R][S][C], optionally divided by sigma
+// ---------------------------------------------------------------------------
+__global__ void pack_weight_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int N, int R, int S, int C,
+                                   long long sn, long long sr, long long ss, long long sc,
+                                   const float* __restrict__ sigma) {
+  long long total = (long long)N * R * S * C;
+  float inv = sigma ? 1.f / sigma[0] : 1.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C);
+    long long t = i / C;
+    int s = (int)(t % S); t /= S;
+    int r = (int)(t % R);
+    int n = (int)(t / R);
+    dst[i] = f2bf(src[n * sn + r * sr + s * ss + c * sc] * inv);
+  }
+}
+
+extern "C" int ried_pack_weight(const float* src, void* dst, int N, int R, int S, int C, long long sn, long long sr,
+                                long long ss, long long sc, const float* sigma, hipStream_t stream) {
+  RIED_CHECK_ARG(src && dst && N > 0 && R > 0 && S > 0 && C > 0, "ried_pack_weight: bad arguments");
+  long long total = (long long)N * R * S * C;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total, EW_THREADS)), dim3(EW_THREADS), 0, stream, src,
+                     (bf16_t*)dst, N, R, S, C, sn, sr, ss, sc, sigma);
+  RIED_CHECK_LAUNCH("ried_pack_weight");
+  return RIED_OK;
+}
+
+// weight-gradient slabs [splitk][taps][Cp][Cg] -> master gradient with arbitrary strides
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splitk, int taps, int Cp, int Cg,
+                                    float* __restrict__ out, long long st, long long sp, long long sg, float scale,
+                                    int accumulate) {
+  long long total = (long long)taps * Cp * Cg;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    float a = 0.f;
+    for (int k = 0; k < splitk; ++k) a += slab[k * total + i];
+    int g = (int)(i % Cg);
+    long long t = i / Cg;
+    int p = (int)(t % Cp);
+    int tap = (int)(t / Cp);
+    float* o = out + tap * st + p * sp + g * sg;
+    a *= scale;
+    *o = accumulate ? *o + a : a;
+  }
+}
+
+extern "C" int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp, int Cg, float* out, long long st,
+                                 long long sp, long long sg, float scale, int accumulate, hipStream_t stream) {
+  RIED_CHECK_ARG(slab && out && splitk > 0 && taps > 0 && Cp > 0 && Cg > 0, "ried_wgrad_reduce: bad arguments");
+  long long total = (long long)taps * Cp * Cg;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(total, EW_THREADS)), dim3(EW_THREADS), 0, stream, slab, splitk,
+                     taps, Cp, Cg, out, st, sp, sg, scale, accumulate);
+  RIED_CHECK_LAUNCH("ried_wgrad_reduce");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// BatchNorm2d, train mode (reference: src/rinet.py:187-193,199-205; torch semantics, eps 1e-5, momentum 0.1)
+// ---------------------------------------------------------------------------
+// stats: [2][C] sum, sum of squares (from the conv epilogue).  save: [2][C] mean, invstd.
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, float count, float eps, float momentum,
+                                   float* __restrict__ save, float* __restrict__ running_mean,
+                                   float* __restrict__ running_var, long long* __restrict__ nbt) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float mean = stats[c] / count;
+    float var = fmaxf(stats[C + c] / count - mean * mean, 0.f);
+    save[c] = mean;
+    save[C + c] = rsqrtf(var + eps);
+    if (running_mean) {
+      float unb = count > 1.f ? var * (count / (count - 1.f)) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+    }
+  }
+  if (c == 0 && nbt) nbt[0] += 1;
+}
+
+extern "C" int ried_bn_finalize(const float* stats, int C, long long count, float eps, float momentum, float* save,
+                                float* running_mean, float* running_var, long long* num_batches_tracked,
+                                hipStream_t stream) {
+  RIED_CHECK_ARG(stats && save && C > 0 && count > 0, "ried_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, stats, C, (float)count, eps,
+                     momentum, save, running_mean, running_var, num_batches_tracked);
+  RIED_CHECK_LAUNCH("ried_bn_finalize");
+  return RIED_OK;
+}
+
+// eval mode: save <- (running_mean, rsqrt(running_var + eps))
+__global__ void bn_eval_stats_kernel(const float* rm, const float* rv, int C, float eps, float* save) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) { save[c] = rm[c]; save[C + c] = rsqrtf(rv[c] + eps); }
+}
+extern "C" int ried_bn_eval_stats(const float* rm, const float* rv, int C, float eps, float* save, hipStream_t stream) {
+  RIED_CHECK_ARG(rm && rv && save && C > 0, "ried_bn_eval_stats: bad arguments");
+  hipLaunchKernelGGL(bn_eval_stats_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, rm, rv, C, eps, save);
+  RIED_CHECK_LAUNCH("ried_bn_eval_stats");
+  return RIED_OK;
+}
+
+// y = relu(gamma*(x-mean)*invstd + beta) [+ y]
+__global__ void bn_apply_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy,
+                                long long npix, int C, const float* __restrict__ save, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, int relu, int accumulate) {
+  const int CC = C >> 3;
+  long long total = npix * CC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long p = i / CC;
+    int c = (int)(i - p * CC) << 3;
+    float f[8];
+    unpack8(ld8(x + p * ldx + c), f);
+    float o[8];
+    if (accumulate) unpack8(ld8(y + p * ldy + c), o);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float a = gamma[c + q] * save[C + c + q];
+      float v = (f[q] - save[c + q]) * a + beta[c + q];
+      if (relu) v = fmaxf(v, 0.f);
+      f[q] = accumulate ? v + o[q] : v;
+    }
+    st8(y + p * ldy + c, pack8(f));
+  }
+}
+
+extern "C" int ried_bn_apply(const void* x, long long ldx, void* y, long long ldy, long long npix, int C,
+                             const float* save, const float* gamma, const float* beta, int relu, int accumulate,
+                             hipStream_t stream) {
+  CHECK_VIEW("ried_bn_apply", x, ldx, C);
+  CHECK_VIEW("ried_bn_apply", y, ldy, C);
+  RIED_CHECK_ARG(save && gamma && beta && npix > 0, "ried_bn_apply: bad arguments");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS)), dim3(EW_THREADS), 0, stream,
+                     (const bf16_t*)x, ldx, (bf16_t*)y, ldy, npix, C, save, gamma, beta, relu, accumulate);
+  RIED_CHECK_LAUNCH("ried_bn_apply");
+  return RIED_OK;
+}
+
+// backward pass 1: sums[0][c] = sum g, sums[1][c] = sum g*xhat, g = dy * [bn(x) > 0]
+__global__ void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x,
+                                     long long ldx, long long npix, int C, const float* __restrict__ save,
+                                     const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+                                     float* __restrict__ sums) {
+  extern __shared__ float lsum[];                 // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lsum[i] = 0.f;
+  __syncthreads();
+  const int CC = C >> 3;
+  // a thread keeps the same channel chunk across its loop when the stride is a multiple of CC
+  long long stride = (long long)gridDim.x * blockDim.x;
+  stride = (stride + CC - 1) / CC * CC;
+  long long total = npix * CC;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < total) {
+    int c = (int)(i % CC) << 3;
+    float a[8], b[8], mean[8], istd[8], s1[8], s2[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mean[q] = save[c + q]; istd[q] = save[C + c + q];
+      a[q] = gamma[c + q] * istd[q]; b[q] = beta[c + q];
+      s1[q] = 0.f; s2[q] = 0.f;
+    }
+    for (; i < total; i += stride) {
+      long long p = i / CC;
+      float g[8], xv[8];
+      unpack8(ld8(dy + p * lddy + c), g);
+      unpack8(ld8(x + p * ldx + c), xv);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float xh = (xv[q] - mean[q]) * istd[q];
+        float pre = (xv[q] - mean[q]) * a[q] + b[q];
+        float gg = (!relu || pre > 0.f) ? g[q] : 0.f;
+        s1[q] += gg; s2[q] += gg * xh;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { atomicAdd(&lsum[c + q], s1[q]); atomicAdd(&lsum[C + c + q], s2[q]); }
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) atomicAdd(&sums[j], lsum[j]);
+}
+
+// backward pass 2: dx = gamma*invstd*(g - s1/n - xhat*s2/n)
+__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x,
+                                    long long ldx, bf16_t* __restrict__ dx, long long lddx, long long npix, int C,
+                                    const float* __restrict__ save, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, int relu, const float* __restrict__ sums) {
+  const int CC = C >> 3;
+  const float invn = 1.f / (float)npix;
+  long long total = npix * CC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long p = i / CC;
+    int c = (int)(i - p * CC) << 3;
+    float g[8], xv[8];
+    unpack8(ld8(dy + p * lddy + c), g);
+    unpack8(ld8(x + p * ldx + c), xv);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float mean = save[c + q], istd = save[C + c + q];
+      float a = gamma[c + q] * istd;
+      float xh = (xv[q] - mean) * istd;
+      float pre = (xv[q] - mean) * a + beta[c + q];
+      float gg = (!relu || pre > 0.f) ? g[q] : 0.f;
+      g[q] = a * (gg - sums[c + q] * invn - xh * sums[C + c + q] * invn);
+    }
+    st8(dx + p * lddx + c, pack8(g));
+  }
+}
+
+__global__ void bn_param_grad_kernel(const float* sums, int C, float* dgamma, float* dbeta, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    dbeta[c] = accumulate ? dbeta[c] + sums[c] : sums[c];
+    dgamma[c] = accumulate ? dgamma[c] + sums[C + c] : sums[C + c];
+  }
+}
+
+// sums must be zero on entry ([2][C] fp32).  dgamma/dbeta may be null (no parameter gradient wanted).
+extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
+                                long long npix, int C, const float* save, const float* gamma, const float* beta,
+                                int relu, float* sums, float* dgamma, float* dbeta, int accumulate,
+                                hipStream_t stream) {
+  CHECK_VIEW("ried_bn_backward", dy, lddy, C);
+  CHECK_VIEW("ried_bn_backward", x, ldx, C);
+  CHECK_VIEW("ried_bn_backward", dx, lddx, C);
+  RIED_CHECK_ARG(save && gamma && beta && sums && npix > 0, "ried_bn_backward: bad arguments");
+  RIED_CHECK_ARG(C <= 4096, "ried_bn_backward: C too large");
+  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, 1024);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), 2 * C * sizeof(float), stream,
+                     (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, sums);
+  if (dgamma && dbeta)
+    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, sums, C, dgamma, dbeta,
+                       accumulate);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS)), dim3(EW_THREADS), 0, stream,
+                     (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (bf16_t*)dx, lddx, npix, C, save, gamma, beta,
+                     relu, sums);
+  RIED_CHECK_LAUNCH("ried_bn_backward");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// pooling / upsampling (reference: src/rinet.py:235,260,266,330,355,361,428; VGG16 MaxPool2d(2,2))
+// ---------------------------------------------------------------------------
+// mode 0: max 3x3 s2 p1   mode 1: max 2x2 s2 p0   mode 2: avg 3x3 s1 p1 (count_include_pad)
+__global__ void pool_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy,
+                                int nimg, int H, int W, int Ho, int Wo, int C, int mode) {
+  const int CC = C >> 3;
+  const int k = mode == 1 ? 2 : 3, s = mode == 2 ? 1 : 2, pad = mode == 1 ? 0 : 1;
+  long long total = (long long)nimg * Ho * Wo * CC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long p = i / CC;
+    int c = (int)(i - p * CC) << 3;
+    int ox = (int)(p % Wo);
+    long long t = p / Wo;
+    int oy = (int)(t % Ho);
+    int n = (int)(t / Ho);
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = mode == 2 ? 0.f : -INFINITY;
+    for (int r = 0; r < k; ++r) {
+      int hi = oy * s - pad + r;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int z = 0; z < k; ++z) {
+        int wi = ox * s - pad + z;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        float f[8];
+        unpack8(ld8(x + ((long long)(n * H + hi) * W + wi) * ldx + c), f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] = mode == 2 ? acc[q] + f[q] : fmaxf(acc[q], f[q]);
+      }
+    }
+    if (mode == 2) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] *= (1.f / 9.f);
+    }
+    st8(y + p * ldy + c, pack8(acc));
+  }
+}
+
+// max-pool backward: the gradient of an output goes to the first maximal element of its window in
+// row-major scan order.  dx is accumulated (+=); one thread owns one INPUT pixel chunk, so no atomics.
+__global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, long long ldx, const bf16_t* __restrict__ dy,
+                                   long long lddy, bf16_t* __restrict__ dx, long long lddx, int nimg, int H, int W,
+                                   int Ho, int Wo, int C, int mode) {
+  const int CC = C >> 3;
+  const int k = mode == 1 ? 2 : 3, s = 2, pad = mode == 1 ? 0 : 1;
+  long long total = (long long)nimg * H * W * CC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long p = i / CC;
+    int c = (int)(i - p * CC) << 3;
+    int wx = (int)(p % W);
+    long long t = p / W;
+    int hy = (int)(t % H);
+    int n = (int)(t / H);
+    float g[8];
+    unpack8(ld8(dx + p * lddx + c), g);
+    float me[8];
+    unpack8(ld8(x + p * ldx + c), me);
+    // output windows that contain (hy, wx)
+    int oy_lo = max(0, (hy + pad - k + s) / s), oy_hi = min(Ho - 1, (hy + pad) / s);
+    int ox_lo = max(0, (wx + pad - k + s) / s), ox_hi = min(Wo - 1, (wx + pad) / s);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy)
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        // is (hy, wx) the first maximum of window (oy, ox)?
+        bool win[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) win[q] = true;
+        for (int r = 0; r < k; ++r) {
+          int hi = oy * s - pad + r;
+          if ((unsigned)hi >= (unsigned)H) continue;
+          for (int z = 0; z < k; ++z) {
+            int wi = ox * s - pad + z;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            if (hi == hy && wi == wx) continue;
+            bool before = hi < hy || (hi == hy && wi < wx);
+            float f[8];
+            unpack8(ld8(x + ((long long)(n * H + hi) * W + wi) * ldx + c), f);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) win[q] = win[q] && (before ? f[q] < me[q] : f[q] <= me[q]);
+          }
+        }
+        float d[8];
+        unpack8(ld8(dy + ((long long)(n * Ho + oy) * Wo + ox) * lddy + c), d);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g[q] += win[q] ? d[q] : 0.f;
+      }
+    st8(dx + p * lddx + c, pack8(g));
+  }
+}
+
+// avg 3x3 s1 p1 backward == the same stencil applied to dy, accumulated into dx
+__global__ void avgpool_bwd_kernel(const bf16_t* __restrict__ dy, long long lddy, bf16_t* __restrict__ dx,
+                                   long long lddx, int nimg, int H, int W, int C) {
+  const int CC = C >> 3;
+  long long total = (long long)nimg * H * W * CC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long p = i / CC;
+    int c = (int)(i - p * CC) << 3;
+    int wx = (int)(p % W);
+    long long t = p / W;
+    int hy = (int)(t % H);
+    int n = (int)(t / H);
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (int r = -1; r <= 1; ++r) {
+      int hi = hy + r;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int z = -1; z <= 1; ++z) {
+        int wi = wx + z;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        float f[8];
+        unpack8(ld8(dy + ((long long)(n * H + hi) * W + wi) * lddy + c), f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += f[q];
+      }
+    }
+    float g[8];
+    unpack8(ld8(dx + p * lddx + c), g);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g[q] += acc[q] * (1.f / 9.f);
+    st8(dx + p * lddx + c, pack8(g));
+  }
+}
+
+extern "C" int ried_pool_fwd(const void* x, long long ldx, void* y, long long ldy, int nimg, int H, int W, int C,
+                             int mode, hipStream_t stream) {
+  CHECK_VIEW("ried_pool_fwd", x, ldx, C);
+  CHECK_VIEW("ried_pool_fwd", y, ldy, C);
+  RIED_CHECK_ARG(mode >= 0 && mode <= 2 && nimg > 0 && H > 0 && W > 0, "ried_pool_fwd: bad arguments");
+  int Ho = mode == 0 ? (H + 2 - 3) / 2 + 1 : mode == 1 ? H / 2 : H;
+  int Wo = mode == 0 ? (W + 2 - 3) / 2 + 1 : mode == 1 ? W / 2 : W;
+  hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((long long)nimg * Ho * Wo * (C / 8), EW_THREADS)),
+                     dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, C, mode);
+  RIED_CHECK_LAUNCH("ried_pool_fwd");
+  return RIED_OK;
+}
+
+// dx += pool backward of dy.  x is the forward input (max modes only).
+extern "C" int ried_pool_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
+                             int nimg, int H, int W, int C, int mode, hipStream_t stream) {
+  CHECK_VIEW("ried_pool_bwd", dy, lddy, C);
+  CHECK_VIEW("ried_pool_bwd", dx, lddx, C);
+  RIED_CHECK_ARG(mode >= 0 && mode <= 2 && nimg > 0 && H > 0 && W > 0, "ried_pool_bwd: bad arguments");
+  int grid = ew_grid((long long)nimg * H * W * (C / 8), EW_THREADS);
+  if (mode == 2) {
+    hipLaunchKernelGGL(avgpool_bwd_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)dy, lddy,
+                       (bf16_t*)dx, lddx, nimg, H, W, C);
+  } else {
+    CHECK_VIEW("ried_pool_bwd", x, ldx, C);
+    int Ho = mode == 0 ? (H + 2 - 3) / 2 + 1 : H / 2;
+    int Wo = mode == 0 ? (W + 2 - 3) / 2 + 1 : W / 2;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx,
+                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, nimg, H, W, Ho, Wo, C, mode);
+  }
+  RIED_CHECK_LAUNCH("ried_pool_bwd");
+  return RIED_OK;
+}
+
+// bilinear x2, align_corners=True: src = dst * (H-1)/(2H-1)
+__global__ void upsample2x_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y,
+                                      long long ldy, int nimg, int H, int W, int C) {
+  const int CC = C >> 3, Ho = 2 * H, Wo = 2 * W;
+  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  long long total = (long long)nimg * Ho * Wo * CC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long p = i / CC;
+    int c = (int)(i - p * CC) << 3;
+    int ox = (int)(p % Wo);
+    long long t = p / Wo;
+    int oy = (int)(t % Ho);
+    int n = (int)(t / Ho);
+    float fy = sy * oy, fx = sx * ox;
+    int y0 = (int)fy, x0 = (int)fx;
+    int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+    float ly = fy - y0, lx = fx - x0;
+    const bf16_t* b = x + (long long)n * H * W * ldx + c;
+    float a[8], bq[8], cq[8], d[8], o[8];
+    unpack8(ld8(b + ((long long)y0 * W + x0) * ldx), a);
+    unpack8(ld8(b + ((long long)y0 * W + x1) * ldx), bq);
+    unpack8(ld8(b + ((long long)y1 * W + x0) * ldx), cq);
+    unpack8(ld8(b + ((long long)y1 * W + x1) * ldx), d);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      o[q] = (1.f - ly) * ((1.f - lx) * a[q] + lx * bq[q]) + ly * ((1.f - lx) * cq[q] + lx * d[q]);
+    st8(y + p * ldy + c, pack8(o));
+  }
+}
+
+// backward as a gather over input pixels: dx[h][w] = sum of the (at most 4x4) outputs that read it
+__global__ void upsample2x_bwd_kernel(const bf16_t* __restrict__ dy, long long lddy, bf16_t* __restrict__ dx,
+                                      long long lddx, int nimg, int H, int W, int C) {
+  const int CC = C >> 3, Ho = 2 * H, Wo = 2 * W;
+  const float sy = Ho > 1 ? (float)(H - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(W - 1) / (float)(Wo - 1) : 0.f;
+  long long total = (long long)nimg * H * W * CC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long p = i / CC;
+    int c = (int)(i - p * CC) << 3;
+    int wx = (int)(p % W);
+    long long t = p / W;
+    int hy = (int)(t % H);
+    int n = (int)(t / H);
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    // outputs oy whose source interval [y0, y0+1] touches hy: scan a safe range
+    int oy_lo = max(0, 2 * hy - 3), oy_hi = min(Ho - 1, 2 * hy + 3);
+    int ox_lo = max(0, 2 * wx - 3), ox_hi = min(Wo - 1, 2 * wx + 3);
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      float fy = sy * oy;
+      int y0 = (int)fy, y1 = min(y0 + 1, H - 1);
+      float ly = fy - y0;
+      float wy = (y0 == hy ? 1.f - ly : 0.f) + (y1 == hy ? ly : 0.f);
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        float fx = sx * ox;
+        int x0 = (int)fx, x1 = min(x0 + 1, W - 1);
+        float lx = fx - x0;
+        float wxx = (x0 == wx ? 1.f - lx : 0.f) + (x1 == wx ? lx : 0.f);
+        if (wxx == 0.f) continue;
+        float f[8];
+        unpack8(ld8(dy + ((long long)(n * Ho + oy) * Wo + ox) * lddy + c), f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += wy * wxx * f[q];
+      }
+    }
+    float g[8];
+    unpack8(ld8(dx + p * lddx + c), g);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g[q] += acc[q];
+    st8(dx + p * lddx + c, pack8(g));
+  }
+}
+
+extern "C" int ried_upsample2x_fwd(const void* x, long long ldx, void* y, long long ldy, int nimg, int H, int W, int C,
+                                   hipStream_t stream) {
+  CHECK_VIEW("ried_upsample2x_fwd", x, ldx, C);
+  CHECK_VIEW("ried_upsample2x_fwd", y, ldy, C);
+  RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0, "ried_upsample2x_fwd: bad arguments");
+  hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(ew_grid((long long)nimg * 4 * H * W * (C / 8), EW_THREADS)),
+                     dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, nimg, H, W, C);
+  RIED_CHECK_LAUNCH("ried_upsample2x_fwd");
+  return RIED_OK;
+}
+
+extern "C" int ried_upsample2x_bwd(const void* dy, long long lddy, void* dx, long long lddx, int nimg, int H, int W,
+                                   int C, hipStream_t stream) {
+  CHECK_VIEW("ried_upsample2x_bwd", dy, lddy, C);
+  CHECK_VIEW("ried_upsample2x_bwd", dx, lddx, C);
+  RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0, "ried_upsample2x_bwd: bad arguments");
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(ew_grid((long long)nimg * H * W * (C / 8), EW_THREADS)),
+                     dim3(EW_THREADS), 0, stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, nimg, H, W, C);
+  RIED_CHECK_LAUNCH("ried_upsample2x_bwd");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generic elementwise helpers
+// ---------------------------------------------------------------------------
+// op 0: out = a                         (copy a view)
+// op 1: out = out + a                   (accumulate)
+// op 2: out = a * (y > 0 ? 1 : slope)   (activation backward from the activation OUTPUT y)
+// op 3: out = out + a * (y > 0 ? 1 : slope)
+// op 4: out = s[0]*a + y                (self-attention combine, s = gamma)
+// op 5: out = s[0]*a                    (scale by a device scalar)
+__global__ void ew_kernel(int op, const bf16_t* __restrict__ a, long long lda, const bf16_t* __restrict__ y,
+                          long long ldy, bf16_t* __restrict__ out, long long ldo, long long npix, int C, float slope,
+                          const float* __restrict__ s) {
+  const int CC = C >> 3;
+  long long total = npix * CC;
+  const float sv = s ? s[0] : 1.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long p = i / CC;
+    int c = (int)(i - p * CC) << 3;
+    float fa[8], fy[8], fo[8];
+    unpack8(ld8(a + p * lda + c), fa);
+    if (op >= 2 && op <= 4) unpack8(ld8(y + p * ldy + c), fy);
+    if (op == 1 || op == 3) unpack8(ld8(out + p * ldo + c), fo);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = fa[q];
+      if (op == 2 || op == 3) v *= (fy[q] > 0.f ? 1.f : slope);
+      if (op == 1 || op == 3) v += fo[q];
+      if (op == 4) v = sv * v + fy[q];
+      if (op == 5) v = sv * v;
+      fa[q] = v;
+    }
+    st8(out + p * ldo + c, pack8(fa));
+  }
+}
+
+extern "C" int ried_ew(int op, const void* a, long long lda, const void* y, long long ldy, void* out, long long ldo,
+                       long long npix, int C, float slope, const float* s, hipStream_t stream) {
+  RIED_CHECK_ARG(op >= 0 && op <= 5, "ried_ew: bad op %d", op);
+  CHECK_VIEW("ried_ew", a, lda, C);
+  CHECK_VIEW("ried_ew", out, ldo, C);
+  if (op >= 2 && op <= 4) CHECK_VIEW("ried_ew", y, ldy, C);
+  RIED_CHECK_ARG(npix > 0, "ried_ew: npix");
+  hipLaunchKernelGGL(ew_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS)), dim3(EW_THREADS), 0, stream, op,
+                     (const bf16_t*)a, lda, (const bf16_t*)y, ldy, (bf16_t*)out, ldo, npix, C, slope, s);
+  RIED_CHECK_LAUNCH("ried_ew");
+  return RIED_OK;
+}
+
+// column sums: out[c] (+)= scale * sum_p a[p][c]     (bias gradients)
+__global__ void colsum_kernel(const bf16_t* __restrict__ a, long long lda, long long npix, int C,
+                              float* __restrict__ out) {
+  extern __shared__ float lsum[];
+  for (int i = threadIdx.x; i < C; i += blockDim.x) lsum[i] = 0.f;
+  __syncthreads();
+  const int CC = C >> 3;
+  long long stride = (long long)gridDim.x * blockDim.x;
+  stride = (stride + CC - 1) / CC * CC;
+  long long total = npix * CC;
+  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < total) {
+    int c = (int)(i % CC) << 3;
+    float s[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s[q] = 0.f;
+    for (; i < total; i += stride) {
+      float f[8];
+      unpack8(ld8(a + (i / CC) * lda + c), f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s[q] += f[q];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) atomicAdd(&lsum[c + q], s[q]);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < C; j += blockDim.x) atomicAdd(&out[j], lsum[j]);
+}
+
+// out must hold the value to accumulate onto (zero it first for a plain sum)
+extern "C" int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, hipStream_t stream) {
+  CHECK_VIEW("ried_colsum", a, lda, C);
+  RIED_CHECK_ARG(out && npix > 0 && C <= 8192, "ried_colsum: bad arguments");
+  hipLaunchKernelGGL(colsum_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS * 8, 512)), dim3(EW_THREADS),
+                     C * sizeof(float), stream, (const bf16_t*)a, lda, npix, C, out);
+  RIED_CHECK_LAUNCH("ried_colsum");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// softmax over the last dimension (reference: src/rinet.py:174) and its backward
+// ---------------------------------------------------------------------------
+// one wave per row; S fp32 [rows][n] -> P bf16 [rows][n]
+__global__ void softmax_fwd_kernel(const float* __restrict__ S, bf16_t* __restrict__ Pm, long long rows, int n) {
+  int lane = threadIdx.x & 63;
+  long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* s = S + row * n;
+  float mx = -INFINITY;
+  for (int j = lane; j < n; j += 64) mx = fmaxf(mx, s[j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < n; j += 64) sum += __expf(s[j] - mx);
+  sum = wave_sum(sum);
+  float inv = 1.f / sum;
+  bf16_t* o = Pm + row * n;
+  for (int j = lane; j < n; j += 64) o[j] = f2bf(__expf(s[j] - mx) * inv);
+}
+
+// dS = P * (dP - sum_j dP*P); dP fp32, P bf16, dS bf16
+__global__ void softmax_bwd_kernel(const float* __restrict__ dP, const bf16_t* __restrict__ Pm,
+                                   bf16_t* __restrict__ dS, long long rows, int n) {
+  int lane = threadIdx.x & 63;
+  long long row = blockIdx.x * (long long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* d = dP + row * n;
+  const bf16_t* p = Pm + row * n;
+  float dot = 0.f;
+  for (int j = lane; j < n; j += 64) dot += d[j] * bf2f(p[j]);
+  dot = wave_sum(dot);
+  bf16_t* o = dS + row * n;
+  for (int j = lane; j < n; j += 64) o[j] = f2bf(bf2f(p[j]) * (d[j] - dot));
+}
+
+extern "C" int ried_softmax_fwd(const float* S, void* P, long long rows, int n, hipStream_t stream) {
+  RIED_CHECK_ARG(S && P && rows > 0 && n > 0, "ried_softmax_fwd: bad arguments");
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, S, (bf16_t*)P, rows, n);
+  RIED_CHECK_LAUNCH("ried_softmax_fwd");
+  return RIED_OK;
+}
+extern "C" int ried_softmax_bwd(const float* dP, const void* P, void* dS, long long rows, int n, hipStream_t stream) {
+  RIED_CHECK_ARG(dP && P && dS && rows > 0 && n > 0, "ried_softmax_bwd: bad arguments");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, dP, (const bf16_t*)P,
+                     (bf16_t*)dS, rows, n);
+  RIED_CHECK_LAUNCH("ried_softmax_bwd");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// dot / sums to device scalars
+// ---------------------------------------------------------------------------
+// out[0] += scale * sum_{p,c} a*b   (b may be null: plain sum of a)
+__global__ void dot_kernel(const bf16_t* __restrict__ a, long long lda, const bf16_t* __restrict__ b, long long ldb,
+                           long long npix, int C, float scale, float* __restrict__ out) {
+  __shared__ float sh[4];
+  const int CC = C >> 3;
+  long long total = npix * CC;
+  float acc = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long p = i / CC;
+    int c = (int)(i - p * CC) << 3;
+    float fa[8], fb[8];
+    unpack8(ld8(a + p * lda + c), fa);
+    if (b) {
+      unpack8(ld8(b + p * ldb + c), fb);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += fa[q] * fb[q];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += fa[q];
+    }
+  }
+  float t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(out, t * scale);
+}
+
+extern "C" int ried_dot(const void* a, long long lda, const void* b, long long ldb, long long npix, int C, float scale,
+                        float* out, hipStream_t stream) {
+  CHECK_VIEW("ried_dot", a, lda, C);
+  if (b) CHECK_VIEW("ried_dot", b, ldb, C);
+  RIED_CHECK_ARG(out && npix > 0, "ried_dot: bad arguments");
+  hipLaunchKernelGGL(dot_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS * 4, 512)), dim3(EW_THREADS), 0, stream,
+                     (const bf16_t*)a, lda, (const bf16_t*)b, ldb, npix, C, scale, out);
+  RIED_CHECK_LAUNCH("ried_dot");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// fused Adam over a flat fp32 parameter buffer (torch.optim.Adam defaults; reference: src/train.py:104-105)
+// step_count is a device int32 incremented by this kernel's first thread AFTER use is not safe across blocks,
+// so the bias corrections are passed by the host, which owns the step counter.
+// ---------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt) {
+  for (long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4; i < n;
+       i += (long long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        mm[q] = b1 * mm[q] + (1.f - b1) * gg[q];
+        vv[q] = b2 * vv[q] + (1.f - b2) * gg[q] * gg[q];
+        float denom = sqrtf(vv[q]) / bc2_sqrt + eps;
+        pp[q] -= (lr / bc1) * (mm[q] / denom);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pp;
+      *reinterpret_cast<f32x4*>(m + i) = mm;
+      *reinterpret_cast<f32x4*>(v + i) = vv;
+    } else {
+      for (long long j = i; j < n; ++j) {
+        float mj = b1 * m[j] + (1.f - b1) * g[j];
+        float vj = b2 * v[j] + (1.f - b2) * g[j] * g[j];
+        m[j] = mj; v[j] = vj;
+        p[j] -= (lr / bc1) * (mj / (sqrtf(vj) / bc2_sqrt + eps));
+      }
+    }
+  }
+}
+
+extern "C" int ried_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
+                         float eps, int step, hipStream_t stream) {
+  RIED_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "ried_adam: bad arguments");
+  RIED_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
+                     ((uintptr_t)v % 16) == 0, "ried_adam: buffers must be 16-byte aligned");
+  double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, EW_THREADS * 4, 2048)), dim3(EW_THREADS), 0, stream, p, g, m, v, n,
+                     lr, b1, b2, eps, (float)bc1, (float)sqrt(bc2));
+  RIED_CHECK_LAUNCH("ried_adam");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// layout / dtype conversion at the module boundary (the reference API is NCHW fp32)
+// ---------------------------------------------------------------------------
+// NCHW fp32 -> NHWC bf16 view (C % 8 == 0)
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long long ldy, int nimg,
+                                    int C, long long HW) {
+  const int CC = C >> 3;
+  long long total = (long long)nimg * HW * CC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // consecutive threads walk hw first so the fp32 reads coalesce
+    long long hw = i % HW;
+    long long t = i / HW;
+    int c = (int)(t % CC) << 3;
+    int n = (int)(t / CC);
+    float f[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) f[q] = x[((long long)n * C + c + q) * HW + hw];
+    st8(y + ((long long)n * HW + hw) * ldy + c, pack8(f));
+  }
+}
+// NHWC bf16 view -> NCHW fp32
+__global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ x, long long ldx, float* __restrict__ y, int nimg,
+                                    int C, long long HW) {
+  const int CC = C >> 3;
+  long long total = (long long)nimg * HW * CC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long hw = i % HW;
+    long long t = i / HW;
+    int c = (int)(t % CC) << 3;
+    int n = (int)(t / CC);
+    float f[8];
+    unpack8(ld8(x + ((long long)n * HW + hw) * ldx + c), f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) y[((long long)n * C + c + q) * HW + hw] = f[q];
+  }
+}
+
+extern "C" int ried_nchw_to_nhwc(const float* x, void* y, long long ldy, int nimg, int C, long long HW,
+                                 hipStream_t stream) {
+  CHECK_VIEW("ried_nchw_to_nhwc", y, ldy, C);
+  RIED_CHECK_ARG(x && nimg > 0 && HW > 0, "ried_nchw_to_nhwc: bad arguments");
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(ew_grid((long long)nimg * HW * (C / 8), EW_THREADS)), dim3(EW_THREADS),
+                     0, stream, x, (bf16_t*)y, ldy, nimg, C, HW);
+  RIED_CHECK_LAUNCH("ried_nchw_to_nhwc");
+  return RIED_OK;
+}
+extern "C" int ried_nhwc_to_nchw(const void* x, long long ldx, float* y, int nimg, int C, long long HW,
+                                 hipStream_t stream) {
+  CHECK_VIEW("ried_nhwc_to_nchw", x, ldx, C);
+  RIED_CHECK_ARG(y && nimg > 0 && HW > 0, "ried_nhwc_to_nchw: bad arguments");
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ew_grid((long long)nimg * HW * (C / 8), EW_THREADS)), dim3(EW_THREADS),
+                     0, stream, (const bf16_t*)x, ldx, y, nimg, C, HW);
+  RIED_CHECK_LAUNCH("ried_nhwc_to_nchw");
+  return RIED_OK;
+}

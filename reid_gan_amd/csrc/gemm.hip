@@ -1,0 +1,604 @@
+// Implicit-GEMM family for gfx950 (CDNA4): bf16 operands, fp32 accumulate on
+// v_mfma_f32_16x16x32_bf16, LDS-staged tiles, 64-wide wavefronts.
+//
+// One kernel template computes   out[n][m] = sum_k A[m][k] * B[n][k]
+// with m the contiguous output dimension (NHWC channels), for four operand
+// shapes:
+//   PLAIN_K   matrix stored [row][k]           (packed weights, q/k, P, dS)
+//   PLAIN_TR  matrix stored [k][row]           (v, dO, dy in weight-gradient)
+//   GATHER_K  NHWC activations, row = output pixel, k = (tap, channel):
+//             the im2col gather of a convolution (or of a transposed
+//             convolution, decomposed by output phase so no MFMA work is
+//             spent on structurally-zero taps)
+//   GATHER_TR NHWC activations, k = output pixel at a fixed tap, row =
+//             channel (the x operand of a weight gradient)
+// [k][row] tiles are consumed with ds_read_b64_tr_b16 (hardware transpose),
+// [row][k] tiles with ds_read_b128.
+//
+// Uses: Conv2d / ConvTranspose2d forward, data gradient and weight gradient
+// of every bf16 layer of the generator, discriminator and VGG16 extractor
+// (reference: src/rinet.py:183-205, 131-148; src/loss.py:69-87), and the
+// batched products of the self-attention layers (src/rinet.py:162-181).
+#include "common.h"
+
+enum { OP_PLAIN_K = 0, OP_PLAIN_TR = 1, OP_GATHER_K = 2, OP_GATHER_TR = 3 };
+
+struct GemmOperand {
+  const bf16_t* p;
+  long long ld;            // plain: stride between rows (K) or between k (TR); gather: pixel stride
+  long long batch_stride;  // plain, batched
+  int rows;                // valid extent along m (operand A) or n (operand B)
+  int nimg, H, W;          // gathered tensor
+  int Ho, Wo;              // logical output grid per image (transposed: the per-phase grid)
+  int kh, kw, sh, sw, ph, pw;
+  int transposed;
+  int C;                   // channels of the gathered tensor
+};
+
+struct GemmEpilogue {
+  void* out;
+  long long ldc, batch_stride, tap_stride;
+  int out_f32;
+  const float* bias;
+  int act;                 // 0 none, 1 relu, 2 leaky relu 0.2
+  float* stats;            // [2][M] sum / sum of squares (fp32 atomics) or null
+  int accumulate;          // out += value
+  const float* gamma;      // out = gamma[0]*value + resid (self-attention) or null
+  const bf16_t* resid;
+  long long ld_resid, resid_batch_stride;
+  float alpha;
+  int phase_mode, Wo_full, HoWo_full, Hq, Wq, sh, sw;   // logical row -> physical pixel
+};
+
+struct GemmParams {
+  GemmOperand A, B;
+  GemmEpilogue E;
+  int M, N;
+  int K;          // per tap (conv: Cin), plain: K, weight gradient: total output pixels
+  int taps;       // conv: kh*kw; otherwise 1 (transposed: computed per phase)
+  int splitk;
+  int tiles_m;
+};
+
+constexpr int BK = 32;
+constexpr int LDK_PAD = 8;
+
+template <int R>
+struct TileGeom {
+  static constexpr int NCH = R / 64;              // 16-byte chunks per thread per tile
+  static constexpr int LDK = BK + LDK_PAD;        // [row][k] image: elements per row
+  static constexpr int LDR = R + 8;               // [k][row] image: elements per k
+  static constexpr int ELEMS = (R * LDK > BK * LDR) ? R * LDK : BK * LDR;
+  static constexpr int CPR = R / 8;               // chunks per k row (TR)
+  static constexpr int KR = 256 / CPR;            // k rows per pass (TR)
+};
+
+// ---------------------------------------------------------------------------
+// operand loaders: global -> registers -> LDS
+// ---------------------------------------------------------------------------
+template <int KIND, int R>
+struct Loader {
+  using G = TileGeom<R>;
+  const bf16_t* ptr[G::NCH];
+  bool valid[G::NCH];
+  int c8;                       // element offset of this thread's chunk inside a row
+  // gather state
+  int gn[G::NCH], gy[G::NCH], gx[G::NCH];
+  int dn, dy, dx;               // mixed-radix increment of BK pixels (GATHER_TR)
+  int kidx[G::NCH];             // PLAIN_TR / GATHER_TR: k row of chunk i inside the tile
+
+  __device__ __forceinline__ void init(const GemmOperand& op, int row0, long long batch, int kbeg,
+                                       int pa, int pb, int r0, int s0) {
+    const int t = threadIdx.x;
+    if constexpr (KIND == OP_PLAIN_K) {
+      c8 = (t & 3) * 8;
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) {
+        int rowg = row0 + (t >> 2) + 64 * i;
+        valid[i] = rowg < op.rows;
+        ptr[i] = op.p + batch * op.batch_stride + (long long)rowg * op.ld + c8;
+      }
+    } else if constexpr (KIND == OP_GATHER_K) {
+      c8 = (t & 3) * 8;
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) {
+        int rowg = row0 + (t >> 2) + 64 * i;
+        valid[i] = rowg < op.rows;
+        int hw = op.Ho * op.Wo;
+        int n = rowg / hw, rem = rowg - n * hw;
+        int oy = rem / op.Wo, ox = rem - oy * op.Wo;
+        gn[i] = n;
+        if (op.transposed) {      // hi = oy + (a + ph - r0)/sh - i_tap
+          gy[i] = oy + (pa + op.ph - r0) / op.sh;
+          gx[i] = ox + (pb + op.pw - s0) / op.sw;
+        } else {                  // hi = oy*sh - ph + r
+          gy[i] = oy * op.sh - op.ph;
+          gx[i] = ox * op.sw - op.pw;
+        }
+        ptr[i] = op.p;
+      }
+    } else if constexpr (KIND == OP_PLAIN_TR) {
+      c8 = (t % G::CPR) * 8;
+      bool cv = row0 + c8 < op.rows;
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) {
+        kidx[i] = t / G::CPR + G::KR * i;
+        valid[i] = cv;
+        ptr[i] = op.p + batch * op.batch_stride + row0 + c8;
+      }
+    } else {  // OP_GATHER_TR: k = output pixel, fixed tap (r0, s0)
+      c8 = (t % G::CPR) * 8;
+      bool cv = row0 + c8 < op.C;
+      int hw = op.Ho * op.Wo;
+      dn = BK / hw;
+      int rem = BK - dn * hw;
+      dy = rem / op.Wo;
+      dx = rem - dy * op.Wo;
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) {
+        kidx[i] = t / G::CPR + G::KR * i;
+        int k = kbeg + kidx[i];
+        int n = k / hw, r2 = k - n * hw;
+        int oy = r2 / op.Wo, ox = r2 - oy * op.Wo;
+        gn[i] = n; gy[i] = oy; gx[i] = ox;
+        valid[i] = cv;
+        ptr[i] = op.p + row0 + c8;
+      }
+    }
+  }
+
+  // GATHER_K: a new tap (ti, tj) -> row pointers and validity
+  __device__ __forceinline__ void set_tap(const GemmOperand& op, int ti, int tj) {
+    if constexpr (KIND == OP_GATHER_K) {
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) {
+        int hi = op.transposed ? gy[i] - ti : gy[i] + ti;
+        int wi = op.transposed ? gx[i] - tj : gx[i] + tj;
+        bool ok = (unsigned)hi < (unsigned)op.H && (unsigned)wi < (unsigned)op.W;
+        // keep the row-valid bit in the sign of gn so it survives tap changes
+        valid[i] = ok && gn[i] >= 0;
+        ptr[i] = op.p + ((long long)(gn[i] * op.H + hi) * op.W + wi) * op.ld + c8;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void mark_invalid_rows() {
+    if constexpr (KIND == OP_GATHER_K) {
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i)
+        if (!valid[i]) gn[i] = -1;
+    }
+  }
+
+  // koff: element offset along k for PLAIN_K (tap offset + kc); kc: offset inside the tap;
+  // kt: k extent of the tap (or end of this block's k range for TR kinds, with kglob the tile's first k)
+  __device__ __forceinline__ void load(const GemmOperand& op, u32x4 (&v)[G::NCH], long long koff, int kc, int kt,
+                                       int kglob, int r0, int s0) {
+    if constexpr (KIND == OP_PLAIN_K) {
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) {
+        bool ok = valid[i] && (kc + c8 < kt);
+        v[i] = ok ? *reinterpret_cast<const u32x4*>(ptr[i] + koff + kc) : u32x4{0, 0, 0, 0};
+      }
+    } else if constexpr (KIND == OP_GATHER_K) {
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) {
+        bool ok = valid[i] && (kc + c8 < kt);
+        v[i] = ok ? *reinterpret_cast<const u32x4*>(ptr[i] + kc) : u32x4{0, 0, 0, 0};
+      }
+    } else if constexpr (KIND == OP_PLAIN_TR) {
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) {
+        int k = kglob + kidx[i];
+        bool ok = valid[i] && k < kt;
+        v[i] = ok ? *reinterpret_cast<const u32x4*>(ptr[i] + (long long)k * op.ld) : u32x4{0, 0, 0, 0};
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) {
+        int k = kglob + kidx[i];
+        int hi = gy[i] * op.sh - op.ph + r0;
+        int wi = gx[i] * op.sw - op.pw + s0;
+        bool ok = valid[i] && k < kt && (unsigned)hi < (unsigned)op.H && (unsigned)wi < (unsigned)op.W;
+        const bf16_t* q = ptr[i] + ((long long)(gn[i] * op.H + hi) * op.W + wi) * op.ld;
+        v[i] = ok ? *reinterpret_cast<const u32x4*>(q) : u32x4{0, 0, 0, 0};
+        // advance this chunk's pixel by BK for the next tile
+        int x = gx[i] + dx, y = gy[i] + dy, n = gn[i] + dn;
+        if (x >= op.Wo) { x -= op.Wo; ++y; }
+        if (y >= op.Ho) { y -= op.Ho; ++n; }
+        gx[i] = x; gy[i] = y; gn[i] = n;
+      }
+    }
+  }
+
+  __device__ __forceinline__ void store(bf16_t* lds, const u32x4 (&v)[G::NCH]) const {
+    const int t = threadIdx.x;
+    if constexpr (KIND == OP_PLAIN_K || KIND == OP_GATHER_K) {
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) {
+        int r = (t >> 2) + 64 * i;
+        *reinterpret_cast<u32x4*>(lds + r * G::LDK + c8) = v[i];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < G::NCH; ++i) *reinterpret_cast<u32x4*>(lds + kidx[i] * G::LDR + c8) = v[i];
+    }
+  }
+};
+
+// fragment of 16 rows x 32 k for the MFMA: lane l holds row (l&15), k = 8*(l>>4) .. +7
+template <int KIND, int R>
+__device__ __forceinline__ bf16x8_t read_frag(const bf16_t* lds, int rowbase, int lane) {
+  using G = TileGeom<R>;
+  if constexpr (KIND == OP_PLAIN_K || KIND == OP_GATHER_K) {
+    const bf16_t* q = lds + (rowbase + (lane & 15)) * G::LDK + (lane >> 4) * 8;
+    return *reinterpret_cast<const bf16x8_t*>(q);
+  } else {
+    // [k][row] image; ds_read_b64_tr_b16 per 16-lane group: lane 4q+p supplies the address of
+    // k row q, rows-of-operand 4p..4p+3; lane i receives operand row i for the 4 k rows.
+    int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const bf16_t* a0 = lds + (8 * g + q) * G::LDR + rowbase + 4 * p;
+    const bf16_t* a1 = a0 + 4 * G::LDR;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf16x8_t, r);
+  }
+}
+
+template <int BM, int BN, int AKIND, int BKIND>
+__global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
+  using GA = TileGeom<BM>;
+  using GB = TileGeom<BN>;
+  constexpr int TM = BM / 32, TN = BN / 32;       // 16x16 tiles per wave (2x2 waves)
+  __shared__ __attribute__((aligned(16))) bf16_t smem[2 * (GA::ELEMS + GB::ELEMS)];
+  constexpr int BUF = GA::ELEMS + GB::ELEMS;        // one buffer: A image then B image
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tm = blockIdx.x % P.tiles_m, tn = blockIdx.x / P.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // block-uniform schedule
+  constexpr bool CONV = (BKIND == OP_GATHER_K);
+  constexpr bool WGRAD = (AKIND == OP_GATHER_TR);
+  int pa = 0, pb = 0, r0 = 0, s0 = 0, tj_n = 1, taps = P.taps;
+  long long batch = 0;
+  int kbeg = 0, kend = P.K;
+  if constexpr (CONV) {
+    if (P.B.transposed) {                 // blockIdx.y = output phase
+      pa = blockIdx.y / P.B.sw; pb = blockIdx.y % P.B.sw;
+      r0 = (pa + P.B.ph) % P.B.sh; s0 = (pb + P.B.pw) % P.B.sw;
+      int nr = (P.B.kh - r0 + P.B.sh - 1) / P.B.sh, ns = (P.B.kw - s0 + P.B.sw - 1) / P.B.sw;
+      tj_n = ns; taps = nr * ns;
+    } else {
+      tj_n = P.B.kw;
+    }
+  } else if constexpr (WGRAD) {           // blockIdx.y = tap, blockIdx.z = k split
+    r0 = blockIdx.y / P.A.kw; s0 = blockIdx.y % P.A.kw;
+    int per = ((P.K + P.splitk - 1) / P.splitk + BK - 1) / BK * BK;
+    kbeg = blockIdx.z * per;
+    kend = min(P.K, kbeg + per);
+  } else {
+    batch = blockIdx.z;
+  }
+
+  Loader<AKIND, BM> la;
+  Loader<BKIND, BN> lb;
+  la.init(P.A, m0, batch, kbeg, pa, pb, r0, s0);
+  lb.init(P.B, n0, batch, kbeg, pa, pb, r0, s0);
+  lb.mark_invalid_rows();
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kt = CONV ? P.K : kend;                      // k extent the loaders mask against
+  const int nchunks = CONV ? (P.K + BK - 1) / BK : (max(kend - kbeg, 0) + BK - 1) / BK;
+  const int nsteps = (CONV ? taps : 1) * nchunks;
+
+  // step state
+  int tap = 0, ti = 0, tj = 0, kc = 0;
+  long long koffA = 0;
+  auto tap_setup = [&]() {
+    if constexpr (CONV) {
+      lb.set_tap(P.B, ti, tj);
+      int r = P.B.transposed ? r0 + ti * P.B.sh : ti;
+      int s = P.B.transposed ? s0 + tj * P.B.sw : tj;
+      koffA = (long long)(r * P.B.kw + s) * P.K;
+    }
+  };
+  auto advance = [&]() {
+    kc += BK;
+    if constexpr (CONV) {
+      if (kc >= P.K) {
+        kc = 0; ++tap; ++tj;
+        if (tj == tj_n) { tj = 0; ++ti; }
+        if (tap < taps) tap_setup();
+      }
+    }
+  };
+
+  u32x4 ra[GA::NCH], rb[GB::NCH];
+  if (nsteps > 0) {
+    tap_setup();
+    la.load(P.A, ra, koffA, kc, kt, kbeg + kc, r0, s0);
+    lb.load(P.B, rb, 0, kc, kt, kbeg + kc, r0, s0);
+    la.store(smem, ra);
+    lb.store(smem + GA::ELEMS, rb);
+    advance();
+  }
+  __syncthreads();
+
+  for (int step = 0; step < nsteps; ++step) {
+    const bf16_t* a_cur = smem + (step & 1) * BUF;
+    const bf16_t* b_cur = a_cur + GA::ELEMS;
+    bf16_t* a_nxt = smem + ((step & 1) ^ 1) * BUF;
+    const bool more = step + 1 < nsteps;
+    if (more) {
+      la.load(P.A, ra, koffA, kc, kt, kbeg + kc, r0, s0);
+      lb.load(P.B, rb, 0, kc, kt, kbeg + kc, r0, s0);
+    }
+    bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = read_frag<AKIND, BM>(a_cur, wm * (BM / 2) + i * 16, lane);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[j] = read_frag<BKIND, BN>(b_cur, wn * (BN / 2) + j * 16, lane);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    if (more) {
+      la.store(a_nxt, ra);
+      lb.store(a_nxt + GA::ELEMS, rb);
+      advance();
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const GemmEpilogue& E = P.E;
+  const float gam = E.gamma ? E.gamma[0] : 0.f;
+  char* outb = (char*)E.out;
+  long long obase = batch * E.batch_stride + (long long)blockIdx.y * E.tap_stride;
+  if constexpr (WGRAD) obase += (long long)blockIdx.z * E.batch_stride;
+  float ssum[TM][4], ssq[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ssum[i][q] = 0.f; ssq[i][q] = 0.f; }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+    bool nok = n < P.N;
+    long long orow = n;
+    if (E.phase_mode) {          // logical (img, hq, wq) of this phase -> physical pixel
+      int hw = E.Hq * E.Wq;
+      int img = n / hw, rem = n - img * hw;
+      int hq = rem / E.Wq, wq = rem - hq * E.Wq;
+      orow = (long long)img * E.HoWo_full + (long long)(hq * E.sh + pa) * E.Wo_full + (wq * E.sw + pb);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] * E.alpha;
+      if (E.stats) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ssum[i][q] += v[q]; ssq[i][q] += v[q] * v[q]; }
+      }
+      if (!(nok && m < P.M)) continue;
+      if (E.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += E.bias[m + q];
+      }
+      if (E.act == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+      } else if (E.act == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.2f * v[q];
+      }
+      if (E.gamma) {
+        const bf16_t* rp = E.resid + batch * E.resid_batch_stride + orow * E.ld_resid + m;
+        u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
+        v[0] = gam * v[0] + bflo(rr[0]); v[1] = gam * v[1] + bfhi(rr[0]);
+        v[2] = gam * v[2] + bflo(rr[1]); v[3] = gam * v[3] + bfhi(rr[1]);
+      }
+      long long off = obase + orow * E.ldc + m;
+      if (E.out_f32) {
+        float* op = (float*)outb + off;
+        if (E.accumulate) {
+          f32x4 o = *reinterpret_cast<f32x4*>(op);
+          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        }
+        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        bf16_t* op = (bf16_t*)outb + off;
+        if (E.accumulate) {
+          u32x2 o = *reinterpret_cast<u32x2*>(op);
+          v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
+        }
+        *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      }
+    }
+  }
+  if (E.stats) {
+    // rows n that are out of range were loaded as zeros, so they add nothing.
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = ssum[i][q], b = ssq[i][q];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
+        if ((lane & 15) == 0 && m < P.M) {
+          atomicAdd(E.stats + m, a);
+          atomicAdd(E.stats + P.M + m, b);
+        }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int AK, int BKIND>
+static void launch(const GemmParams& P, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL((igemm_kernel<BM, BN, AK, BKIND>), grid, dim3(256), 0, s, P);
+}
+
+static void default_epilogue(GemmEpilogue& E) {
+  memset(&E, 0, sizeof(E));
+  E.alpha = 1.f;
+}
+
+// Conv2d forward (transposed = 0) or ConvTranspose2d forward / strided-conv data gradient
+// (transposed = 1).  x: NHWC bf16 [nimg][H][W][ldx], channels 0..Cin-1 used.
+// w: packed bf16 [Cout][kh][kw][Cin].  y: NHWC [nimg][Ho][Wo][ldy], channels 0..Cout-1 written.
+extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
+                           int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                           int transposed, const float* bias, int act, float* stats, int accumulate, int out_f32,
+                           hipStream_t stream) {
+  RIED_CHECK_ARG(x && w && y, "ried_conv2d: null pointer");
+  RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
+  RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
+                 "ried_conv2d: channels/strides must be multiples of 8 (Cin=%d Cout=%d ldx=%lld ldy=%lld)", Cin, Cout,
+                 ldx, ldy);
+  RIED_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w % 16) == 0 && ((uintptr_t)y % 8) == 0,
+                 "ried_conv2d: pointers must be 16-byte aligned");
+  RIED_CHECK_ARG(kh > 0 && kw > 0 && sh > 0 && sw > 0 && ph >= 0 && pw >= 0, "ried_conv2d: bad kernel geometry");
+  GemmParams P;
+  memset(&P, 0, sizeof(P));
+  default_epilogue(P.E);
+  int phases = 1;
+  int Hl = Ho, Wl = Wo;
+  if (transposed) {
+    RIED_CHECK_ARG(Ho % sh == 0 && Wo % sw == 0, "ried_conv2d: transposed mode needs Ho %% sh == 0");
+    // the strided convolution that this transposes must map (Ho, Wo) -> (H, W); covers output_padding
+    RIED_CHECK_ARG((Ho + 2 * ph - kh) / sh + 1 == H && (Wo + 2 * pw - kw) / sw + 1 == W && Ho + 2 * ph >= kh &&
+                       Wo + 2 * pw >= kw,
+                   "ried_conv2d: transposed output size mismatch (H=%d Ho=%d)", H, Ho);
+    RIED_CHECK_ARG(kh >= sh && kw >= sw, "ried_conv2d: transposed mode needs kernel >= stride");
+    phases = sh * sw;
+    Hl = Ho / sh; Wl = Wo / sw;
+    P.E.phase_mode = 1;
+    P.E.Wo_full = Wo; P.E.HoWo_full = Ho * Wo; P.E.Hq = Hl; P.E.Wq = Wl; P.E.sh = sh; P.E.sw = sw;
+  } else {
+    RIED_CHECK_ARG(Ho == (H + 2 * ph - kh) / sh + 1 && Wo == (W + 2 * pw - kw) / sw + 1,
+                   "ried_conv2d: output size mismatch (H=%d Ho=%d)", H, Ho);
+  }
+  long long npix = (long long)nimg * Hl * Wl;
+  RIED_CHECK_ARG(npix < (1ll << 30) && (long long)nimg * H * W < (1ll << 30), "ried_conv2d: too many pixels");
+  P.A.p = (const bf16_t*)w; P.A.ld = (long long)kh * kw * Cin; P.A.rows = Cout;
+  P.B.p = (const bf16_t*)x; P.B.ld = ldx; P.B.rows = (int)npix;
+  P.B.nimg = nimg; P.B.H = H; P.B.W = W; P.B.Ho = Hl; P.B.Wo = Wl;
+  P.B.kh = kh; P.B.kw = kw; P.B.sh = sh; P.B.sw = sw; P.B.ph = ph; P.B.pw = pw;
+  P.B.transposed = transposed; P.B.C = Cin;
+  P.M = Cout; P.N = (int)npix; P.K = Cin; P.taps = kh * kw; P.splitk = 1;
+  P.E.out = y; P.E.ldc = ldy; P.E.out_f32 = out_f32; P.E.bias = bias; P.E.act = act; P.E.stats = stats;
+  P.E.accumulate = accumulate;
+  if (Cout <= 64) {
+    P.tiles_m = ceil_div(Cout, 64);
+    dim3 grid(P.tiles_m * ceil_div(npix, 128), phases, 1);
+    launch<64, 128, OP_PLAIN_K, OP_GATHER_K>(P, grid, stream);
+  } else {
+    P.tiles_m = ceil_div(Cout, 128);
+    dim3 grid(P.tiles_m * ceil_div(npix, 128), phases, 1);
+    launch<128, 128, OP_PLAIN_K, OP_GATHER_K>(P, grid, stream);
+  }
+  RIED_CHECK_LAUNCH("ried_conv2d");
+  return RIED_OK;
+}
+
+// Weight gradient partial sums.  g: the tensor that is gathered through the kernel window
+// (the conv input; for a ConvTranspose2d layer, the output gradient), NHWC bf16 [nimg][H][W][ldg], Cg channels.
+// p: the tensor indexed by output pixel (conv: output gradient; ConvTranspose2d: the layer input),
+// NHWC bf16 [nimg][Ho][Wo][ldp], Cp channels.   slab: fp32 [splitk][kh*kw][Cp][Cg].
+extern "C" int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg, int H, int W, const void* p,
+                                 long long ldp, int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw,
+                                 float* slab, int splitk, hipStream_t stream) {
+  RIED_CHECK_ARG(g && p && slab, "ried_conv2d_wgrad: null pointer");
+  RIED_CHECK_ARG(Cg % 8 == 0 && Cp % 8 == 0 && ldg % 8 == 0 && ldp % 8 == 0, "ried_conv2d_wgrad: channels %% 8");
+  RIED_CHECK_ARG(((uintptr_t)g % 16) == 0 && ((uintptr_t)p % 16) == 0 && ((uintptr_t)slab % 16) == 0,
+                 "ried_conv2d_wgrad: alignment");
+  RIED_CHECK_ARG(Ho == (H + 2 * ph - kh) / sh + 1 && Wo == (W + 2 * pw - kw) / sw + 1,
+                 "ried_conv2d_wgrad: output size mismatch");
+  RIED_CHECK_ARG(splitk >= 1 && splitk <= 65535, "ried_conv2d_wgrad: bad splitk");
+  long long npix = (long long)nimg * Ho * Wo;
+  RIED_CHECK_ARG(npix < (1ll << 30) && (long long)nimg * H * W < (1ll << 30), "ried_conv2d_wgrad: too many pixels");
+  GemmParams P;
+  memset(&P, 0, sizeof(P));
+  default_epilogue(P.E);
+  P.A.p = (const bf16_t*)g; P.A.ld = ldg; P.A.rows = Cg; P.A.C = Cg;
+  P.A.nimg = nimg; P.A.H = H; P.A.W = W; P.A.Ho = Ho; P.A.Wo = Wo;
+  P.A.kh = kh; P.A.kw = kw; P.A.sh = sh; P.A.sw = sw; P.A.ph = ph; P.A.pw = pw;
+  P.B.p = (const bf16_t*)p; P.B.ld = ldp; P.B.rows = Cp;
+  P.M = Cg; P.N = Cp; P.K = (int)npix; P.taps = 1; P.splitk = splitk;
+  P.E.out = slab; P.E.ldc = Cg; P.E.out_f32 = 1;
+  P.E.tap_stride = (long long)Cp * Cg;
+  P.E.batch_stride = (long long)kh * kw * Cp * Cg;      // per split
+  if (Cg <= 64 && Cp <= 64) {
+    P.tiles_m = 1;
+    dim3 grid(1, kh * kw, splitk);
+    launch<64, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
+  } else {
+    P.tiles_m = ceil_div(Cg, 128);
+    dim3 grid(P.tiles_m * ceil_div(Cp, 128), kh * kw, splitk);
+    launch<128, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
+  }
+  RIED_CHECK_LAUNCH("ried_conv2d_wgrad");
+  return RIED_OK;
+}
+
+// Batched out[b][n][m] = alpha * sum_k A[b][m][k] B[b][n][k]  (+ gamma*value + resid, or accumulate).
+// a_tr / b_tr: the operand is stored [k][row] instead of [row][k].
+extern "C" int ried_bgemm(const void* A, long long lda, long long bsa, int a_tr, const void* B, long long ldb,
+                          long long bsb, int b_tr, int M, int N, int K, int batch, void* out, long long ldc,
+                          long long bsc, int out_f32, float alpha, const float* gamma, const void* resid,
+                          long long ld_resid, long long bs_resid, int accumulate, hipStream_t stream) {
+  RIED_CHECK_ARG(A && B && out, "ried_bgemm: null pointer");
+  RIED_CHECK_ARG(M % 8 == 0 && N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0,
+                 "ried_bgemm: M, N, K and strides must be multiples of 8 (M=%d N=%d K=%d)", M, N, K);
+  RIED_CHECK_ARG(bsa % 8 == 0 && bsb % 8 == 0 && bsc % 4 == 0, "ried_bgemm: batch strides must be multiples of 8");
+  RIED_CHECK_ARG(((uintptr_t)A % 16) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                 "ried_bgemm: alignment");
+  RIED_CHECK_ARG(batch >= 1 && batch <= 65535, "ried_bgemm: bad batch");
+  RIED_CHECK_ARG(!gamma || resid, "ried_bgemm: gamma needs resid");
+  GemmParams P;
+  memset(&P, 0, sizeof(P));
+  default_epilogue(P.E);
+  P.A.p = (const bf16_t*)A; P.A.ld = lda; P.A.batch_stride = bsa; P.A.rows = M;
+  P.B.p = (const bf16_t*)B; P.B.ld = ldb; P.B.batch_stride = bsb; P.B.rows = N;
+  P.M = M; P.N = N; P.K = K; P.taps = 1; P.splitk = 1;
+  P.E.out = out; P.E.ldc = ldc; P.E.batch_stride = bsc; P.E.out_f32 = out_f32; P.E.alpha = alpha;
+  P.E.gamma = gamma; P.E.resid = (const bf16_t*)resid; P.E.ld_resid = ld_resid; P.E.resid_batch_stride = bs_resid;
+  P.E.accumulate = accumulate;
+  bool small = (M <= 64);
+  int bm = small ? 64 : 128;
+  P.tiles_m = ceil_div(M, bm);
+  dim3 grid(P.tiles_m * ceil_div(N, 128), 1, batch);
+  if (small) {
+    if (!a_tr && !b_tr) launch<64, 128, OP_PLAIN_K, OP_PLAIN_K>(P, grid, stream);
+    else if (a_tr && !b_tr) launch<64, 128, OP_PLAIN_TR, OP_PLAIN_K>(P, grid, stream);
+    else if (a_tr && b_tr) launch<64, 128, OP_PLAIN_TR, OP_PLAIN_TR>(P, grid, stream);
+    else launch<64, 128, OP_PLAIN_K, OP_PLAIN_TR>(P, grid, stream);
+  } else {
+    if (!a_tr && !b_tr) launch<128, 128, OP_PLAIN_K, OP_PLAIN_K>(P, grid, stream);
+    else if (a_tr && !b_tr) launch<128, 128, OP_PLAIN_TR, OP_PLAIN_K>(P, grid, stream);
+    else if (a_tr && b_tr) launch<128, 128, OP_PLAIN_TR, OP_PLAIN_TR>(P, grid, stream);
+    else launch<128, 128, OP_PLAIN_K, OP_PLAIN_TR>(P, grid, stream);
+  }
+  RIED_CHECK_LAUNCH("ried_bgemm");
+  return RIED_OK;
+}

@@ -1,0 +1,513 @@
+// Layer-specific kernels that are not bf16 implicit GEMMs:
+//  * single-input-channel 3x3 convolutions reading the fp32 CT image (generator conv1, discriminator layer 0,
+//    VGG16 layer 0 with its three identical input channels folded into one) - K = 9 is bandwidth bound;
+//  * the generator's 33->1 output convolution, kept in fp32 because its first input is the raw HU image;
+//  * spectral normalisation (one power iteration) and its backward term;
+//  * perceptual MSE taps, hinge / generator loss scalars, constant-gradient fills.
+// Reference: src/rinet.py:20,55,70,131-148; src/loss.py:132-197; torch/nn/utils/spectral_norm.py:92-114.
+#include "common.h"
+
+#define SP_THREADS 256
+
+__device__ __forceinline__ void unpack8s(const u32x4& v, float (&f)[8]) {
+  f[0] = bflo(v[0]); f[1] = bfhi(v[0]); f[2] = bflo(v[1]); f[3] = bfhi(v[1]);
+  f[4] = bflo(v[2]); f[5] = bfhi(v[2]); f[6] = bflo(v[3]); f[7] = bfhi(v[3]);
+}
+
+// ---------------------------------------------------------------------------
+// 3x3, pad 1, one input channel (fp32 image), stride 1 or 2
+// ---------------------------------------------------------------------------
+// y[p][co] = act( sum_t w[co][t] * (xin*in_scale + in_shift)[p@t] / sigma + bias[co] ), zero padding after the affine.
+template <int COUT>
+__global__ __launch_bounds__(SP_THREADS) void conv_c1_fwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sigma,
+    const float* __restrict__ bias, bf16_t* __restrict__ y, long long ldy, int nimg, int H, int W, int Ho, int Wo,
+    int stride, float in_scale, float in_shift, int act, float* __restrict__ stats) {
+  constexpr int CC = COUT / 8;
+  constexpr int PPB = SP_THREADS / CC;              // pixels per block pass
+  __shared__ float wl[9][COUT];
+  __shared__ float lst[2][COUT];
+  const float inv = sigma ? 1.f / sigma[0] : 1.f;
+  for (int i = threadIdx.x; i < 9 * COUT; i += SP_THREADS) wl[i % 9][i / 9] = w[i] * inv;
+  if (stats) for (int i = threadIdx.x; i < 2 * COUT; i += SP_THREADS) (&lst[0][0])[i] = 0.f;
+  __syncthreads();
+  const int c = (threadIdx.x % CC) * 8;
+  const int pl = threadIdx.x / CC;
+  const long long npix = (long long)nimg * Ho * Wo;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  for (long long p = (long long)blockIdx.x * PPB + pl; p < npix; p += (long long)gridDim.x * PPB) {
+    int ox = (int)(p % Wo);
+    long long t = p / Wo;
+    int oy = (int)(t % Ho);
+    int n = (int)(t / Ho);
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    const float* xi = x + (long long)n * H * W;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int hi = oy * stride - 1 + r;
+#pragma unroll
+      for (int z = 0; z < 3; ++z) {
+        int wi = ox * stride - 1 + z;
+        bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        float v = ok ? xi[(long long)hi * W + wi] * in_scale + in_shift : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += v * wl[r * 3 + z][c + q];
+      }
+    }
+    if (stats) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { s1[q] += acc[q]; s2[q] += acc[q] * acc[q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = acc[q] + (bias ? bias[c + q] : 0.f);
+      if (act == 1) v = fmaxf(v, 0.f);
+      else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+      acc[q] = v;
+    }
+    *reinterpret_cast<u32x4*>(y + p * ldy + c) =
+        u32x4{pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
+  }
+  if (stats) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { atomicAdd(&lst[0][c + q], s1[q]); atomicAdd(&lst[1][c + q], s2[q]); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * COUT; i += SP_THREADS) atomicAdd(&stats[i], (&lst[0][0])[i]);
+  }
+}
+
+extern "C" int ried_conv_c1_fwd(const float* x, const float* w, const float* sigma, const float* bias, void* y,
+                                long long ldy, int nimg, int H, int W, int Cout, int stride, float in_scale,
+                                float in_shift, int act, float* stats, hipStream_t stream) {
+  RIED_CHECK_ARG(x && w && y && nimg > 0 && H > 0 && W > 0, "ried_conv_c1_fwd: bad arguments");
+  RIED_CHECK_ARG(stride == 1 || stride == 2, "ried_conv_c1_fwd: stride must be 1 or 2");
+  RIED_CHECK_ARG(ldy % 8 == 0 && ldy >= Cout && ((uintptr_t)y % 16) == 0, "ried_conv_c1_fwd: output view");
+  int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  long long npix = (long long)nimg * Ho * Wo;
+  if (Cout == 32) {
+    int grid = ew_grid(npix, SP_THREADS / 4 * 4, 2048);
+    hipLaunchKernelGGL(conv_c1_fwd_kernel<32>, dim3(grid), dim3(SP_THREADS), 0, stream, x, w, sigma, bias,
+                       (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats);
+  } else if (Cout == 64) {
+    int grid = ew_grid(npix, SP_THREADS / 8 * 4, 2048);
+    hipLaunchKernelGGL(conv_c1_fwd_kernel<64>, dim3(grid), dim3(SP_THREADS), 0, stream, x, w, sigma, bias,
+                       (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats);
+  } else {
+    RIED_CHECK_ARG(false, "ried_conv_c1_fwd: Cout must be 32 or 64 (got %d)", Cout);
+  }
+  RIED_CHECK_LAUNCH("ried_conv_c1_fwd");
+  return RIED_OK;
+}
+
+// dw[co][t] += sum_p dy[p][co] * xaff[p@t]      (fp32 atomics onto a zeroed / accumulating [Cout][9] buffer)
+template <int COUT>
+__global__ __launch_bounds__(SP_THREADS) void conv_c1_wgrad_kernel(const float* __restrict__ x,
+                                                                   const bf16_t* __restrict__ dy, long long lddy,
+                                                                   int nimg, int H, int W, int Ho, int Wo, int stride,
+                                                                   float in_scale, float in_shift,
+                                                                   float* __restrict__ dw) {
+  constexpr int CC = COUT / 8;
+  constexpr int PPB = SP_THREADS / CC;
+  __shared__ float ldw[COUT * 9];
+  for (int i = threadIdx.x; i < COUT * 9; i += SP_THREADS) ldw[i] = 0.f;
+  __syncthreads();
+  const int c = (threadIdx.x % CC) * 8;
+  const int pl = threadIdx.x / CC;
+  const long long npix = (long long)nimg * Ho * Wo;
+  float acc[8][9];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[q][t] = 0.f;
+  for (long long p = (long long)blockIdx.x * PPB + pl; p < npix; p += (long long)gridDim.x * PPB) {
+    int ox = (int)(p % Wo);
+    long long t2 = p / Wo;
+    int oy = (int)(t2 % Ho);
+    int n = (int)(t2 / Ho);
+    float g[8];
+    unpack8s(*reinterpret_cast<const u32x4*>(dy + p * lddy + c), g);
+    const float* xi = x + (long long)n * H * W;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int hi = oy * stride - 1 + r;
+#pragma unroll
+      for (int z = 0; z < 3; ++z) {
+        int wi = ox * stride - 1 + z;
+        bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        float v = ok ? xi[(long long)hi * W + wi] * in_scale + in_shift : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q][r * 3 + z] += g[q] * v;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) atomicAdd(&ldw[(c + q) * 9 + t], acc[q][t]);
+  __syncthreads();
+  for (int i = threadIdx.x; i < COUT * 9; i += SP_THREADS) atomicAdd(&dw[i], ldw[i]);
+}
+
+extern "C" int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy, int nimg, int H, int W, int Cout,
+                                  int stride, float in_scale, float in_shift, float* dw, hipStream_t stream) {
+  RIED_CHECK_ARG(x && dy && dw && nimg > 0, "ried_conv_c1_wgrad: bad arguments");
+  RIED_CHECK_ARG(stride == 1 || stride == 2, "ried_conv_c1_wgrad: stride must be 1 or 2");
+  RIED_CHECK_ARG(lddy % 8 == 0 && lddy >= Cout && ((uintptr_t)dy % 16) == 0, "ried_conv_c1_wgrad: dy view");
+  int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  long long npix = (long long)nimg * Ho * Wo;
+  int grid = ew_grid(npix, 64 * 16, 512);
+  if (Cout == 32)
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel<32>, dim3(grid), dim3(SP_THREADS), 0, stream, x, (const bf16_t*)dy, lddy,
+                       nimg, H, W, Ho, Wo, stride, in_scale, in_shift, dw);
+  else if (Cout == 64)
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel<64>, dim3(grid), dim3(SP_THREADS), 0, stream, x, (const bf16_t*)dy, lddy,
+                       nimg, H, W, Ho, Wo, stride, in_scale, in_shift, dw);
+  else
+    RIED_CHECK_ARG(false, "ried_conv_c1_wgrad: Cout must be 32 or 64");
+  RIED_CHECK_LAUNCH("ried_conv_c1_wgrad");
+  return RIED_OK;
+}
+
+// stride 1 data gradient: dx[h][w] (+)= scale * sum_{co,r,s} dy[h+1-r][w+1-s][co] * w[co][r][s] / sigma
+// 8 lanes per pixel (one 8-channel chunk each), reduced with shuffles.
+template <int COUT>
+__global__ __launch_bounds__(SP_THREADS) void conv_c1_dgrad_kernel(const bf16_t* __restrict__ dy, long long lddy,
+                                                                   const float* __restrict__ w,
+                                                                   const float* __restrict__ sigma,
+                                                                   float* __restrict__ dx, int nimg, int H, int W,
+                                                                   float scale, int accumulate) {
+  constexpr int CC = COUT / 8;
+  constexpr int PPB = SP_THREADS / CC;
+  __shared__ float wl[9][COUT];
+  const float inv = sigma ? 1.f / sigma[0] : 1.f;
+  for (int i = threadIdx.x; i < 9 * COUT; i += SP_THREADS) wl[i % 9][i / 9] = w[i] * inv;
+  __syncthreads();
+  const int cc = threadIdx.x % CC, c = cc * 8;
+  const int pl = threadIdx.x / CC;
+  const long long npix = (long long)nimg * H * W;
+  const long long pend = (npix + PPB - 1) / PPB * PPB;     // keep all lanes in the shuffles
+  for (long long p = (long long)blockIdx.x * PPB + pl; p < pend; p += (long long)gridDim.x * PPB) {
+    float acc = 0.f;
+    if (p < npix) {
+      int wx = (int)(p % W);
+      long long t = p / W;
+      int hy = (int)(t % H);
+      int n = (int)(t / H);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        int ho = hy + 1 - r;
+        if ((unsigned)ho >= (unsigned)H) continue;
+#pragma unroll
+        for (int z = 0; z < 3; ++z) {
+          int wo = wx + 1 - z;
+          if ((unsigned)wo >= (unsigned)W) continue;
+          float g[8];
+          unpack8s(*reinterpret_cast<const u32x4*>(dy + ((long long)(n * H + ho) * W + wo) * lddy + c), g);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc += g[q] * wl[r * 3 + z][c + q];
+        }
+      }
+    }
+#pragma unroll
+    for (int o = CC / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (cc == 0 && p < npix) dx[p] = accumulate ? dx[p] + scale * acc : scale * acc;
+  }
+}
+
+extern "C" int ried_conv_c1_dgrad(const void* dy, long long lddy, const float* w, const float* sigma, float* dx,
+                                  int nimg, int H, int W, int Cout, float scale, int accumulate, hipStream_t stream) {
+  RIED_CHECK_ARG(dy && w && dx && nimg > 0, "ried_conv_c1_dgrad: bad arguments");
+  RIED_CHECK_ARG(lddy % 8 == 0 && lddy >= Cout && ((uintptr_t)dy % 16) == 0, "ried_conv_c1_dgrad: dy view");
+  RIED_CHECK_ARG(Cout == 64, "ried_conv_c1_dgrad: Cout must be 64");
+  long long npix = (long long)nimg * H * W;
+  hipLaunchKernelGGL(conv_c1_dgrad_kernel<64>, dim3(ew_grid(npix, 32, 4096)), dim3(SP_THREADS), 0, stream,
+                     (const bf16_t*)dy, lddy, w, sigma, dx, nimg, H, W, scale, accumulate);
+  RIED_CHECK_LAUNCH("ried_conv_c1_dgrad");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// generator output conv: out[p] = w[0]*x[p] + sum_c w[1+c]*h[p][c]   (src/rinet.py:70,90), C = 32
+// ---------------------------------------------------------------------------
+__global__ void out_conv_fwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ h, long long ldh,
+                                    const float* __restrict__ w, float* __restrict__ out, long long npix) {
+  // 4 lanes per pixel, 8 channels each
+  long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  long long nthreads = (long long)gridDim.x * blockDim.x;
+  long long pend = (npix * 4 + nthreads - 1) / nthreads * nthreads;
+  for (long long i = gid; i < pend; i += nthreads) {
+    long long p = i >> 2;
+    int c = (int)(i & 3) * 8;
+    float acc = 0.f;
+    if (p < npix) {
+      float f[8];
+      unpack8s(*reinterpret_cast<const u32x4*>(h + p * ldh + c), f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += f[q] * w[1 + c + q];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if ((i & 3) == 0 && p < npix) out[p] = acc + w[0] * x[p];
+  }
+}
+
+// dh[p][c] = w[1+c]*dout[p];  dw[0] += sum dout*x;  dw[1+c] += sum dout*h[p][c]
+__global__ void out_conv_bwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ h, long long ldh,
+                                    const float* __restrict__ w, const float* __restrict__ dout,
+                                    bf16_t* __restrict__ dh, long long lddh, float* __restrict__ dw, long long npix) {
+  __shared__ float ldw[33];
+  if (threadIdx.x < 33) ldw[threadIdx.x] = 0.f;
+  __syncthreads();
+  const int c = (threadIdx.x & 3) * 8;
+  float wv[8], s[8], s0 = 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { wv[q] = w[1 + c + q]; s[q] = 0.f; }
+  long long nthreads = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix * 4; i += nthreads) {
+    long long p = i >> 2;
+    float d = dout[p];
+    float f[8], o[8];
+    unpack8s(*reinterpret_cast<const u32x4*>(h + p * ldh + c), f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { s[q] += d * f[q]; o[q] = d * wv[q]; }
+    if (c == 0) s0 += d * x[p];
+    *reinterpret_cast<u32x4*>(dh + p * lddh + c) =
+        u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) atomicAdd(&ldw[1 + c + q], s[q]);
+  if (c == 0) atomicAdd(&ldw[0], s0);
+  __syncthreads();
+  if (threadIdx.x < 33) atomicAdd(&dw[threadIdx.x], ldw[threadIdx.x]);
+}
+
+extern "C" int ried_out_conv_fwd(const float* x, const void* h, long long ldh, const float* w, float* out,
+                                 long long npix, hipStream_t stream) {
+  RIED_CHECK_ARG(x && h && w && out && npix > 0 && ldh % 8 == 0 && ldh >= 32 && ((uintptr_t)h % 16) == 0,
+                 "ried_out_conv_fwd: bad arguments");
+  hipLaunchKernelGGL(out_conv_fwd_kernel, dim3(ew_grid(npix * 4, SP_THREADS, 2048)), dim3(SP_THREADS), 0, stream, x,
+                     (const bf16_t*)h, ldh, w, out, npix);
+  RIED_CHECK_LAUNCH("ried_out_conv_fwd");
+  return RIED_OK;
+}
+
+// dw (33 floats) is accumulated onto; zero it first for a plain gradient.
+extern "C" int ried_out_conv_bwd(const float* x, const void* h, long long ldh, const float* w, const float* dout,
+                                 void* dh, long long lddh, float* dw, long long npix, hipStream_t stream) {
+  RIED_CHECK_ARG(x && h && w && dout && dh && dw && npix > 0 && ldh % 8 == 0 && lddh % 8 == 0 &&
+                     ((uintptr_t)h % 16) == 0 && ((uintptr_t)dh % 16) == 0, "ried_out_conv_bwd: bad arguments");
+  hipLaunchKernelGGL(out_conv_bwd_kernel, dim3(ew_grid(npix * 4, SP_THREADS * 4, 1024)), dim3(SP_THREADS), 0, stream,
+                     x, (const bf16_t*)h, ldh, w, dout, (bf16_t*)dh, lddh, dw, npix);
+  RIED_CHECK_LAUNCH("ried_out_conv_bwd");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// spectral normalisation, one power iteration (torch/nn/utils/spectral_norm.py:97-113)
+// W: fp32 [R][K] (weight_orig viewed as a matrix).  scratch: fp32 [K + R + 2], zeroed by the first kernel's caller.
+// ---------------------------------------------------------------------------
+// t[k] = sum_r W[r][k] u[r];  n2[0] += sum t^2
+__global__ void sn_wt_u_kernel(const float* __restrict__ Wm, const float* __restrict__ u, int R, int K,
+                               float* __restrict__ t, float* __restrict__ n2) {
+  __shared__ float sh[4];
+  int k = blockIdx.x * blockDim.x + threadIdx.x;
+  float acc = 0.f;
+  if (k < K)
+    for (int r = 0; r < R; ++r) acc += Wm[(long long)r * K + k] * u[r];
+  if (k < K) t[k] = acc;
+  float s = block_sum_256(k < K ? acc * acc : 0.f, sh);
+  if (threadIdx.x == 0) atomicAdd(n2, s);
+}
+// s[r] = sum_k W[r][k] t[k];  n2[1] += sum s^2     (one wave per row)
+__global__ void sn_w_v_kernel(const float* __restrict__ Wm, const float* __restrict__ t, int R, int K,
+                              float* __restrict__ s, float* __restrict__ n2) {
+  int lane = threadIdx.x & 63;
+  int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc += Wm[(long long)r * K + k] * t[k];
+  acc = wave_sum(acc);
+  if (lane == 0) { s[r] = acc; atomicAdd(n2 + 1, acc * acc); }
+}
+// power_iter = 1: v = t/|t|, Wv = s/|t|, u = Wv/|Wv|, sigma = u.Wv
+// power_iter = 0: t held v already (s = W v): sigma = u.s with the stored u
+__global__ void sn_finish_kernel(const float* __restrict__ t, const float* __restrict__ s, const float* __restrict__ n2,
+                                 int R, int K, float eps, int power_iter, float* __restrict__ u, float* __restrict__ v,
+                                 float* __restrict__ sigma) {
+  __shared__ float sh[4];
+  if (power_iter) {
+    float nt = fmaxf(sqrtf(n2[0]), eps);
+    float nwv = sqrtf(n2[1]) / nt;                  // |W v|
+    float nu = fmaxf(nwv, eps);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) v[k] = t[k] / nt;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) u[r] = (s[r] / nt) / nu;
+    if (threadIdx.x == 0) sigma[0] = nwv * nwv / nu;
+  } else {
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) acc += u[r] * s[r];
+    float d = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) sigma[0] = d;
+  }
+}
+
+extern "C" int ried_sn_sigma(const float* Wm, int R, int K, float* u, float* v, float* sigma, float* scratch,
+                             int power_iter, float eps, hipStream_t stream) {
+  RIED_CHECK_ARG(Wm && u && v && sigma && scratch && R > 0 && K > 0, "ried_sn_sigma: bad arguments");
+  float* t = scratch;
+  float* s = scratch + K;
+  float* n2 = scratch + K + R;
+  hipError_t e = hipMemsetAsync(n2, 0, 2 * sizeof(float), stream);
+  if (e != hipSuccess) { ried_set_error("ried_sn_sigma: memset failed"); return RIED_ERR_HIP; }
+  if (power_iter) {
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, stream, Wm, u, R, K, t, n2);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, stream, Wm, t, R, K, s, n2);
+  } else {
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, stream, Wm, v, R, K, s, n2);
+  }
+  hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(256), 0, stream, t, s, n2, R, K, eps, power_iter, u, v, sigma);
+  RIED_CHECK_LAUNCH("ried_sn_sigma");
+  return RIED_OK;
+}
+
+// dW_orig = (dWsn - (sum(dWsn * W)/sigma) * u v^T) / sigma
+__global__ void sn_bwd_dot_kernel(const float* __restrict__ dWsn, const float* __restrict__ Wm, long long n,
+                                  float* __restrict__ dot) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    acc += dWsn[i] * Wm[i];
+  float d = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(dot, d);
+}
+__global__ void sn_bwd_apply_kernel(const float* __restrict__ dWsn, const float* __restrict__ u,
+                                    const float* __restrict__ v, const float* __restrict__ sigma,
+                                    const float* __restrict__ dot, int R, int K, float* __restrict__ dW,
+                                    int accumulate) {
+  long long n = (long long)R * K;
+  float sg = sigma[0];
+  float coef = dot[0] / sg;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    int r = (int)(i / K), k = (int)(i - (long long)r * K);
+    float g = (dWsn[i] - coef * u[r] * v[k]) / sg;
+    dW[i] = accumulate ? dW[i] + g : g;
+  }
+}
+
+extern "C" int ried_sn_backward(const float* dWsn, const float* Wm, const float* u, const float* v,
+                                const float* sigma, int R, int K, float* dW, float* scratch1, int accumulate,
+                                hipStream_t stream) {
+  RIED_CHECK_ARG(dWsn && Wm && u && v && sigma && dW && scratch1 && R > 0 && K > 0, "ried_sn_backward: bad arguments");
+  hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), stream);
+  if (e != hipSuccess) { ried_set_error("ried_sn_backward: memset failed"); return RIED_ERR_HIP; }
+  long long n = (long long)R * K;
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(ew_grid(n, 1024, 512)), dim3(256), 0, stream, dWsn, Wm, n, scratch1);
+  hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(ew_grid(n, 256, 2048)), dim3(256), 0, stream, dWsn, u, v, sigma,
+                     scratch1, R, K, dW, accumulate);
+  RIED_CHECK_LAUNCH("ried_sn_backward");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// perceptual-loss tap: loss[0] += loss_scale * sum (a-b)^2 ;  g (+)= grad_scale * (a-b)
+// a = features of the prediction, b = features of the target (src/loss.py:184-189)
+// ---------------------------------------------------------------------------
+__global__ void mse_tap_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long long n8,
+                               float loss_scale, float* __restrict__ loss, bf16_t* __restrict__ g, float grad_scale,
+                               int accumulate) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    float fa[8], fb[8], fg[8];
+    unpack8s(*reinterpret_cast<const u32x4*>(a + i * 8), fa);
+    unpack8s(*reinterpret_cast<const u32x4*>(b + i * 8), fb);
+    if (g && accumulate) unpack8s(*reinterpret_cast<const u32x4*>(g + i * 8), fg);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float d = fa[q] - fb[q];
+      acc += d * d;
+      fa[q] = grad_scale * d + ((g && accumulate) ? fg[q] : 0.f);
+    }
+    if (g)
+      *reinterpret_cast<u32x4*>(g + i * 8) =
+          u32x4{pack2bf(fa[0], fa[1]), pack2bf(fa[2], fa[3]), pack2bf(fa[4], fa[5]), pack2bf(fa[6], fa[7])};
+  }
+  float t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, t * loss_scale);
+}
+
+// a, b, g: contiguous bf16 arrays of n elements (n % 8 == 0)
+extern "C" int ried_mse_tap(const void* a, const void* b, long long n, float loss_scale, float* loss, void* g,
+                            float grad_scale, int accumulate, hipStream_t stream) {
+  RIED_CHECK_ARG(a && b && n > 0 && n % 8 == 0, "ried_mse_tap: bad arguments");
+  RIED_CHECK_ARG(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)g % 16) == 0,
+                 "ried_mse_tap: alignment");
+  hipLaunchKernelGGL(mse_tap_kernel, dim3(ew_grid(n / 8, SP_THREADS * 2, 1024)), dim3(SP_THREADS), 0, stream,
+                     (const bf16_t*)a, (const bf16_t*)b, n / 8, loss_scale, loss, (bf16_t*)g, grad_scale, accumulate);
+  RIED_CHECK_LAUNCH("ried_mse_tap");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
+// loss scalars (src/loss.py:141-142, 154-155, 194).  sc is a small fp32 device array:
+//  in : sc[0] = mean(pos)  sc[1] = mean(neg)
+//  out: sc[2] = dloss = relu(1-mean(pos)) + relu(1+mean(neg))
+//       sc[3] = d dloss / d pos_i = -[1-mean(pos) > 0]/n     sc[4] = d dloss / d neg_i = +[1+mean(neg) > 0]/n
+// ---------------------------------------------------------------------------
+__global__ void dloss_scalars_kernel(float* sc, float inv_n) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float a = 1.f - sc[0], b = 1.f + sc[1];
+    sc[2] = fmaxf(a, 0.f) + fmaxf(b, 0.f);
+    sc[3] = a > 0.f ? -inv_n : 0.f;
+    sc[4] = b > 0.f ? inv_n : 0.f;
+  }
+}
+extern "C" int ried_dloss_scalars(float* sc, long long n_per_half, hipStream_t stream) {
+  RIED_CHECK_ARG(sc && n_per_half > 0, "ried_dloss_scalars: bad arguments");
+  hipLaunchKernelGGL(dloss_scalars_kernel, dim3(1), dim3(64), 0, stream, sc, 1.f / (float)n_per_half);
+  RIED_CHECK_LAUNCH("ried_dloss_scalars");
+  return RIED_OK;
+}
+
+//  in : sc[1] = mean(neg), sc[5] = perceptual mean-of-5 MSE, sc[6] = mean SSIM
+//  out: sc[7] = dssim = (1-ssim)/2, sc[8] = gen = 1-mean(neg), sc[9] = gloss = wv*sc[5] + ws*sc[7] + wg*sc[8]
+__global__ void gloss_scalars_kernel(float* sc, float wv, float ws, float wg) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    sc[7] = (1.f - sc[6]) * 0.5f;
+    sc[8] = 1.f - sc[1];
+    sc[9] = wv * sc[5] + ws * sc[7] + wg * sc[8];
+  }
+}
+extern "C" int ried_gloss_scalars(float* sc, float wv, float ws, float wg, hipStream_t stream) {
+  RIED_CHECK_ARG(sc != nullptr, "ried_gloss_scalars: bad arguments");
+  hipLaunchKernelGGL(gloss_scalars_kernel, dim3(1), dim3(64), 0, stream, sc, wv, ws, wg);
+  RIED_CHECK_LAUNCH("ried_gloss_scalars");
+  return RIED_OK;
+}
+
+// out[p][c] = (s ? s[0] : 1) * value
+__global__ void fill_kernel(bf16_t* __restrict__ out, long long ldo, long long npix, int C, const float* s,
+                            float value) {
+  const int CC = C >> 3;
+  float v = (s ? s[0] : 1.f) * value;
+  unsigned pk = pack2bf(v, v);
+  u32x4 vv{pk, pk, pk, pk};
+  long long total = npix * CC;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    long long p = i / CC;
+    int c = (int)(i - p * CC) << 3;
+    *reinterpret_cast<u32x4*>(out + p * ldo + c) = vv;
+  }
+}
+extern "C" int ried_fill(void* out, long long ldo, long long npix, int C, const float* s, float value,
+                         hipStream_t stream) {
+  RIED_CHECK_ARG(out && npix > 0 && C % 8 == 0 && ldo % 8 == 0 && ((uintptr_t)out % 16) == 0,
+                 "ried_fill: bad arguments");
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(npix * (C / 8), SP_THREADS, 2048)), dim3(SP_THREADS), 0, stream,
+                     (bf16_t*)out, ldo, npix, C, s, value);
+  RIED_CHECK_LAUNCH("ried_fill");
+  return RIED_OK;
+}

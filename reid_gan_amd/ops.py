@@ -1,0 +1,233 @@
+"""Typed wrappers over the C ABI: torch tensors in, kernel launches on torch's current HIP stream.
+
+PyTorch is used only as the owner of device memory and streams; every
+computation below is a hand-written HIP kernel in libried_gan.so.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from ._lib import lib
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("reid_gan_amd runs on an MI355X (ROCm) device only; no GPU is visible and there is "
+                           "no CPU fallback")
+    lib.load()
+
+
+@dataclass
+class View:
+    """Channels [0, C) of an NHWC bf16 tensor: pixel p's channels start at ptr + 2*p*ld."""
+    base: torch.Tensor          # keeps the storage alive
+    ptr: int
+    ld: int
+    C: int
+    N: int
+    H: int
+    W: int
+
+    @property
+    def npix(self) -> int:
+        return self.N * self.H * self.W
+
+    def slice(self, c0: int, c1: int) -> "View":
+        assert 0 <= c0 < c1 <= self.C and c0 % 8 == 0 and c1 % 8 == 0, (c0, c1, self.C)
+        return View(self.base, self.ptr + 2 * c0, self.ld, c1 - c0, self.N, self.H, self.W)
+
+    def images(self, n0: int, n1: int) -> "View":
+        assert 0 <= n0 < n1 <= self.N
+        return View(self.base, self.ptr + 2 * n0 * self.H * self.W * self.ld, self.ld, self.C, n1 - n0, self.H, self.W)
+
+    def torch(self) -> torch.Tensor:
+        """The view as an (N,H,W,C) bf16 tensor (debug / tests)."""
+        off = (self.ptr - self.base.data_ptr()) // 2
+        flat = self.base.reshape(-1)
+        return flat.as_strided((self.N, self.H, self.W, self.C),
+                               (self.H * self.W * self.ld, self.W * self.ld, self.ld, 1), off)
+
+
+def new_view(N: int, H: int, W: int, C: int, device="cuda", zero: bool = False) -> View:
+    t = (torch.zeros if zero else torch.empty)((N, H, W, C), dtype=BF16, device=device)
+    return View(t, t.data_ptr(), C, C, N, H, W)
+
+
+# --------------------------------------------------------------------------- GEMM family
+def conv2d(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed=False, bias=None, act=0,
+           stats=None, accumulate=False, out_f32=False):
+    lib.ried_conv2d(x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C, kh, kw, sh, sw, ph, pw,
+                    int(transposed), _p(bias), act, _p(stats), int(accumulate), int(out_f32), _stream())
+
+
+def conv2d_wgrad(g: View, p: View, kh, kw, sh, sw, ph, pw, slab: torch.Tensor, splitk: int):
+    lib.ried_conv2d_wgrad(g.ptr, g.ld, g.C, g.N, g.H, g.W, p.ptr, p.ld, p.C, p.H, p.W, kh, kw, sh, sw, ph, pw,
+                          _p(slab), splitk, _stream())
+
+
+def wgrad_reduce(slab, splitk, taps, Cp, Cg, out: torch.Tensor, st, sp, sg, scale=1.0, accumulate=False):
+    lib.ried_wgrad_reduce(_p(slab), splitk, taps, Cp, Cg, _p(out), st, sp, sg, scale, int(accumulate), _stream())
+
+
+def bgemm(A, lda, bsa, a_tr, B, ldb, bsb, b_tr, M, N, K, batch, out, ldc, bsc, out_f32=False, alpha=1.0,
+          gamma=None, resid=None, ld_resid=0, bs_resid=0, accumulate=False):
+    lib.ried_bgemm(A, lda, bsa, int(a_tr), B, ldb, bsb, int(b_tr), M, N, K, batch, out, ldc, bsc, int(out_f32),
+                   alpha, _p(gamma), resid, ld_resid, bs_resid, int(accumulate), _stream())
+
+
+def pack_weight(src: torch.Tensor, dst: torch.Tensor, N, R, S, C, sn, sr, ss, sc, sigma=None):
+    lib.ried_pack_weight(_p(src), _p(dst), N, R, S, C, sn, sr, ss, sc, _p(sigma), _stream())
+
+
+# --------------------------------------------------------------------------- batch norm
+def bn_finalize(stats, C, count, save, rm=None, rv=None, nbt=None, eps=1e-5, momentum=0.1):
+    lib.ried_bn_finalize(_p(stats), C, count, eps, momentum, _p(save), _p(rm), _p(rv), _p(nbt), _stream())
+
+
+def bn_eval_stats(rm, rv, C, save, eps=1e-5):
+    lib.ried_bn_eval_stats(_p(rm), _p(rv), C, eps, _p(save), _stream())
+
+
+def bn_apply(x: View, y: View, save, gamma, beta, relu=True, accumulate=False):
+    lib.ried_bn_apply(x.ptr, x.ld, y.ptr, y.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta), int(relu),
+                      int(accumulate), _stream())
+
+
+def bn_backward(dy: View, x: View, dx: View, save, gamma, beta, sums, dgamma=None, dbeta=None, relu=True,
+                accumulate=False):
+    lib.ried_bn_backward(dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta),
+                         int(relu), _p(sums), _p(dgamma), _p(dbeta), int(accumulate), _stream())
+
+
+# --------------------------------------------------------------------------- pooling etc.
+POOL_MAX3S2, POOL_MAX2S2, POOL_AVG3 = 0, 1, 2
+
+
+def pool_fwd(x: View, y: View, mode: int):
+    lib.ried_pool_fwd(x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, mode, _stream())
+
+
+def pool_bwd(x: Optional[View], dy: View, dx: View, mode: int):
+    lib.ried_pool_bwd(None if x is None else x.ptr, 0 if x is None else x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, dx.N,
+                      dx.H, dx.W, dx.C, mode, _stream())
+
+
+def upsample2x_fwd(x: View, y: View):
+    lib.ried_upsample2x_fwd(x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, _stream())
+
+
+def upsample2x_bwd(dy: View, dx: View):
+    lib.ried_upsample2x_bwd(dy.ptr, dy.ld, dx.ptr, dx.ld, dx.N, dx.H, dx.W, dx.C, _stream())
+
+
+EW_COPY, EW_ADD, EW_ACTBWD, EW_ACTBWD_ADD, EW_AXPY, EW_SCALE = range(6)
+
+
+def ew(op: int, a: View, out: View, y: Optional[View] = None, slope: float = 0.0, s=None):
+    lib.ried_ew(op, a.ptr, a.ld, None if y is None else y.ptr, 0 if y is None else y.ld, out.ptr, out.ld, a.npix,
+                a.C, slope, _p(s), _stream())
+
+
+def colsum(a: View, out: torch.Tensor):
+    lib.ried_colsum(a.ptr, a.ld, a.npix, a.C, _p(out), _stream())
+
+
+def dot(a: View, b: Optional[View], scale: float, out: torch.Tensor):
+    lib.ried_dot(a.ptr, a.ld, None if b is None else b.ptr, 0 if b is None else b.ld, a.npix, a.C, scale, _p(out),
+                 _stream())
+
+
+def fill(out: View, value: float, s=None):
+    lib.ried_fill(out.ptr, out.ld, out.npix, out.C, _p(s), value, _stream())
+
+
+def softmax_fwd(S: torch.Tensor, P: torch.Tensor, rows: int, n: int):
+    lib.ried_softmax_fwd(_p(S), _p(P), rows, n, _stream())
+
+
+def softmax_bwd(dP: torch.Tensor, P: torch.Tensor, dS: torch.Tensor, rows: int, n: int):
+    lib.ried_softmax_bwd(_p(dP), _p(P), _p(dS), rows, n, _stream())
+
+
+def nchw_to_nhwc(x: torch.Tensor, y: View):
+    lib.ried_nchw_to_nhwc(_p(x), y.ptr, y.ld, y.N, y.C, y.H * y.W, _stream())
+
+
+def nhwc_to_nchw(x: View, y: torch.Tensor):
+    lib.ried_nhwc_to_nchw(x.ptr, x.ld, _p(y), x.N, x.C, x.H * x.W, _stream())
+
+
+def adam(p, g, m, v, lr, step, b1=0.01, b2=0.99, eps=1e-8):
+    lib.ried_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, _stream())
+
+
+# --------------------------------------------------------------------------- special layers
+def conv_c1_fwd(x: torch.Tensor, w, y: View, stride, sigma=None, bias=None, in_scale=1.0, in_shift=0.0, act=0,
+                stats=None):
+    n, h, wd = x.shape[0], x.shape[-2], x.shape[-1]
+    lib.ried_conv_c1_fwd(_p(x), _p(w), _p(sigma), _p(bias), y.ptr, y.ld, n, h, wd, y.C, stride, in_scale, in_shift,
+                         act, _p(stats), _stream())
+
+
+def conv_c1_wgrad(x: torch.Tensor, dy: View, stride, dw: torch.Tensor, in_scale=1.0, in_shift=0.0):
+    n, h, wd = x.shape[0], x.shape[-2], x.shape[-1]
+    lib.ried_conv_c1_wgrad(_p(x), dy.ptr, dy.ld, n, h, wd, dy.C, stride, in_scale, in_shift, _p(dw), _stream())
+
+
+def conv_c1_dgrad(dy: View, w, dx: torch.Tensor, sigma=None, scale=1.0, accumulate=False):
+    lib.ried_conv_c1_dgrad(dy.ptr, dy.ld, _p(w), _p(sigma), _p(dx), dy.N, dy.H, dy.W, dy.C, scale, int(accumulate),
+                           _stream())
+
+
+def out_conv_fwd(x: torch.Tensor, h: View, w: torch.Tensor, out: torch.Tensor):
+    lib.ried_out_conv_fwd(_p(x), h.ptr, h.ld, _p(w), _p(out), h.npix, _stream())
+
+
+def out_conv_bwd(x, h: View, w, dout, dh: View, dw):
+    lib.ried_out_conv_bwd(_p(x), h.ptr, h.ld, _p(w), _p(dout), dh.ptr, dh.ld, _p(dw), h.npix, _stream())
+
+
+def sn_sigma(Wm: torch.Tensor, R, K, u, v, sigma, scratch, power_iter=True, eps=1e-12):
+    lib.ried_sn_sigma(_p(Wm), R, K, _p(u), _p(v), _p(sigma), _p(scratch), int(power_iter), eps, _stream())
+
+
+def sn_backward(dWsn, Wm, u, v, sigma, R, K, dW, scratch1, accumulate=False):
+    lib.ried_sn_backward(_p(dWsn), _p(Wm), _p(u), _p(v), _p(sigma), R, K, _p(dW), _p(scratch1), int(accumulate),
+                         _stream())
+
+
+def mse_tap(a_ptr, b_ptr, n, loss_scale, loss, g_ptr, grad_scale, accumulate=False):
+    lib.ried_mse_tap(a_ptr, b_ptr, n, loss_scale, _p(loss), g_ptr, grad_scale, int(accumulate), _stream())
+
+
+def dloss_scalars(sc: torch.Tensor, n_per_half: int):
+    lib.ried_dloss_scalars(_p(sc), n_per_half, _stream())
+
+
+def gloss_scalars(sc: torch.Tensor, wv, ws, wg):
+    lib.ried_gloss_scalars(_p(sc), wv, ws, wg, _stream())
+
+
+def ssim_fwd(a, b, ref, c1, c2, sums, gmap=None, clamp=None):
+    n, h, w = ref.shape[0], ref.shape[-2], ref.shape[-1]
+    lo, hi = clamp if clamp is not None else (0.0, 0.0)
+    lib.ried_ssim_fwd(_p(a), _p(b), _p(ref), n, h, w, c1, c2, int(clamp is not None), lo, hi, _p(sums), _p(gmap),
+                      _stream())
+
+
+def ssim_bwd(a, ref, gmap, scale, da, scale_dev=None, accumulate=False):
+    n, h, w = ref.shape[0], ref.shape[-2], ref.shape[-1]
+    lib.ried_ssim_bwd(_p(a), _p(ref), _p(gmap), n, h, w, scale, _p(scale_dev), _p(da), int(accumulate), _stream())

@@ -1,0 +1,453 @@
+"""Kernel-level parity on the GPU: each C-ABI entry point against a torch CPU fp32 statement of the same op.
+
+Inputs are rounded to bf16 first, so the only differences are the fp32 accumulation order and the bf16
+rounding of the output; the tolerance (1.5e-2 of the output's max, 3e-3 for fp32 outputs) is stated per check.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from reid_gan_amd import ops
+from reid_gan_amd.ops import View
+
+DEV = "cuda"
+
+
+def r(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16).float()
+
+
+def to_view(x_nchw) -> View:
+    t = x_nchw.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    n, h, w, c = t.shape
+    return View(t, t.data_ptr(), c, c, n, h, w)
+
+
+def from_view(v: View):
+    return v.torch().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b, tol=1.5e-2, what=""):
+    a, b = a.double(), b.double()
+    scale = max(b.abs().max().item(), 1e-20)
+    err = (a - b).abs().max().item()
+    assert err <= tol * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+
+
+def pack(w_oikk):
+    """(Cout,Cin,kh,kw) fp32 -> bf16 [Cout][kh][kw][Cin] through the library's pack kernel."""
+    co, ci, kh, kw = w_oikk.shape
+    src = w_oikk.contiguous().to(DEV)
+    dst = torch.empty(co * kh * kw * ci, dtype=torch.bfloat16, device=DEV)
+    ops.pack_weight(src, dst, co, kh, kw, ci, ci * kh * kw, kw, 1, kh * kw)
+    return dst
+
+
+CONV_CASES = [
+    # cin, cout, k, stride, pad, H
+    (64, 128, (3, 3), 1, (1, 1), 16),
+    (32, 64, (3, 3), 2, (1, 1), 16),
+    (16, 32, (3, 3), 1, (1, 1), 8),
+    (48, 48, (3, 3), 1, (1, 1), 8),
+    (256, 64, (1, 1), 1, (0, 0), 8),
+    (64, 64, (1, 7), 1, (0, 3), 8),
+    (128, 128, (7, 1), 1, (3, 0), 4),
+    (224, 192, (3, 3), 1, (1, 1), 4),
+    (512, 160, (1, 1), 1, (0, 0), 4),
+    (64, 16, (1, 1), 1, (0, 0), 16),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,H", CONV_CASES)
+def test_conv2d_forward_stats(cin, cout, k, s, p, H):
+    x = r(3, cin, H, H, seed=1).abs()
+    w = r(cout, cin, *k, seed=2, scale=(cin * k[0] * k[1]) ** -0.5)
+    ref = F.conv2d(x, w, None, s, p)
+    xv = to_view(x)
+    Ho, Wo = ref.shape[-2:]
+    yv = ops.new_view(3, Ho, Wo, cout)
+    stats = torch.zeros(2, cout, device=DEV)
+    ops.conv2d(xv, pack(w), yv, k[0], k[1], s, s, p[0], p[1], stats=stats)
+    close(from_view(yv), ref, what="y")
+    close(stats[0].cpu(), ref.sum((0, 2, 3)), 3e-3 * 10, "sum")
+    close(stats[1].cpu(), (ref * ref).sum((0, 2, 3)), 3e-3, "sumsq")
+
+
+def test_conv2d_bias_act_slice_accumulate():
+    x = r(2, 64, 8, 8, seed=3)
+    w = r(128, 64, 3, 3, seed=4, scale=0.05)
+    b = r(128, seed=5)
+    ref = F.leaky_relu(F.conv2d(x, w, b, 2, 1), 0.2)
+    big = ops.new_view(2, 4, 4, 256, zero=True)
+    ops.conv2d(to_view(x), pack(w), big.slice(64, 192), 3, 3, 2, 2, 1, 1, bias=b.to(DEV), act=2)
+    got = from_view(big)
+    close(got[:, 64:192], ref, what="slice")
+    assert got[:, :64].abs().max() == 0 and got[:, 192:].abs().max() == 0
+    ops.conv2d(to_view(x), pack(w), big.slice(64, 192), 3, 3, 2, 2, 1, 1, bias=b.to(DEV), act=2, accumulate=True)
+    close(from_view(big)[:, 64:192], 2 * ref, what="accumulate")
+
+
+TCONV_CASES = [
+    # cin, cout, k, stride, pad, H(in), out_pad
+    (96, 32, (4, 4), 2, (1, 1), 8, 0),
+    (192, 64, (4, 4), 2, (1, 1), 4, 0),
+    (64, 32, (3, 3), 2, (1, 1), 8, 1),      # data gradient of a 3x3 s2 p1 conv (16 -> 8)
+    (128, 128, (1, 7), 1, (0, 3), 4, 0),
+    (48, 32, (3, 3), 1, (1, 1), 8, 0),
+    (1024, 64, (1, 1), 1, (0, 0), 4, 0),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,H,op", TCONV_CASES)
+def test_conv2d_transposed(cin, cout, k, s, p, H, op):
+    x = r(2, cin, H, H, seed=6)
+    w = r(cin, cout, *k, seed=7, scale=(cin * k[0] * k[1]) ** -0.5)       # ConvTranspose2d layout
+    ref = F.conv_transpose2d(x, w, None, s, p, output_padding=op)
+    Ho, Wo = ref.shape[-2:]
+    yv = ops.new_view(2, Ho, Wo, cout)
+    wp = pack(w.permute(1, 0, 2, 3))                                      # -> [Cout][kh][kw][Cin]
+    ops.conv2d(to_view(x), wp, yv, k[0], k[1], s, s, p[0], p[1], transposed=True)
+    close(from_view(yv), ref, what="y")
+
+
+WGRAD_CASES = [
+    (64, 128, (3, 3), 1, (1, 1), 8, 5),
+    (32, 64, (3, 3), 2, (1, 1), 16, 3),
+    (16, 32, (3, 3), 1, (1, 1), 8, 2),
+    (256, 64, (1, 1), 1, (0, 0), 8, 4),
+    (64, 64, (1, 7), 1, (0, 3), 8, 1),
+    (192, 192, (3, 1), 1, (1, 0), 4, 2),
+    (512, 1024, (1, 1), 1, (0, 0), 4, 1),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,H,splitk", WGRAD_CASES)
+def test_conv2d_wgrad(cin, cout, k, s, p, H, splitk):
+    x = r(3, cin, H, H, seed=8).requires_grad_(False)
+    w = r(cout, cin, *k, seed=9).requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = r(*y.shape, seed=10)
+    (ref,) = torch.autograd.grad(y, w, dy)
+    taps = k[0] * k[1]
+    slab = torch.empty(splitk * taps * cout * cin, device=DEV)
+    ops.conv2d_wgrad(to_view(x), to_view(dy), k[0], k[1], s, s, p[0], p[1], slab, splitk)
+    out = torch.zeros(cout, cin, *k, device=DEV)
+    ops.wgrad_reduce(slab, splitk, taps, cout, cin, out, 1, cin * taps, taps)
+    close(out.cpu(), ref, 3e-3, "dW")
+
+
+def test_deconv_wgrad():
+    cin, cout, H = 96, 32, 8
+    x = r(2, cin, H, H, seed=11)
+    w = r(cin, cout, 4, 4, seed=12).requires_grad_(True)
+    y = F.conv_transpose2d(x, w, None, 2, 1)
+    dy = r(*y.shape, seed=13)
+    (ref,) = torch.autograd.grad(y, w, dy)
+    slab = torch.empty(4 * 16 * cin * cout, device=DEV)
+    # gathered tensor = dy (the deconv output side), pixel-indexed tensor = x
+    ops.conv2d_wgrad(to_view(dy), to_view(x), 4, 4, 2, 2, 1, 1, slab, 4)
+    out = torch.zeros(cin, cout, 4, 4, device=DEV)
+    ops.wgrad_reduce(slab, 4, 16, cin, cout, out, 1, cout * 16, 16)
+    close(out.cpu(), ref, 3e-3, "dW")
+
+
+@pytest.mark.parametrize("a_tr,b_tr", [(0, 0), (1, 0), (1, 1), (0, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 32), (64, 64, 64), (32, 256, 256), (512, 64, 64), (256, 1024, 32)])
+def test_bgemm(a_tr, b_tr, M, N, K):
+    batch = 3
+    A = r(batch, M, K, seed=14)
+    B = r(batch, N, K, seed=15)
+    ref = torch.einsum("bmk,bnk->bnm", A, B)
+    Ad = (A.transpose(1, 2) if a_tr else A).contiguous().to(torch.bfloat16).to(DEV)
+    Bd = (B.transpose(1, 2) if b_tr else B).contiguous().to(torch.bfloat16).to(DEV)
+    out = torch.empty(batch, N, M, device=DEV)
+    ops.bgemm(Ad.data_ptr(), M if a_tr else K, M * K, a_tr, Bd.data_ptr(), N if b_tr else K, N * K, b_tr, M, N, K,
+              batch, out.data_ptr(), M, N * M, out_f32=True)
+    close(out.cpu(), ref, 3e-3, "C")
+
+
+def test_bgemm_asymmetric_identity():
+    """A = I with an asymmetric B catches a transposed accumulator write."""
+    M = N = K = 64
+    A = torch.eye(M).unsqueeze(0)
+    B = (torch.arange(N * K).reshape(1, N, K) % 251).float()
+    out = torch.empty(1, N, M, device=DEV)
+    ops.bgemm(A.to(torch.bfloat16).to(DEV).data_ptr(), K, M * K, 0, B.to(torch.bfloat16).to(DEV).data_ptr(), K, N * K,
+              0, M, N, K, 1, out.data_ptr(), M, N * M, out_f32=True)
+    assert torch.equal(out.cpu(), torch.einsum("bmk,bnk->bnm", A, B))
+
+
+def test_bn_forward_backward():
+    N, C, H = 4, 48, 8
+    x = r(N, C, H, H, seed=16) * 2 + 0.5
+    gamma, beta = r(C, seed=17) + 1.0, r(C, seed=18) * 0.3
+    xr = x.clone().requires_grad_(True)
+    g2, b2 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.relu(F.batch_norm(xr, rm, rv, g2, b2, True, 0.1, 1e-5))
+    dy = r(*y.shape, seed=19)
+    y.backward(dy)
+    xv = to_view(x)
+    stats = torch.stack([x.sum((0, 2, 3)), (x * x).sum((0, 2, 3))]).to(DEV)
+    save = torch.empty(2, C, device=DEV)
+    rm_d, rv_d = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    ops.bn_finalize(stats, C, N * H * H, save, rm_d, rv_d, nbt)
+    yv = ops.new_view(N, H, H, C)
+    ops.bn_apply(xv, yv, save, gamma.to(DEV), beta.to(DEV))
+    close(from_view(yv), y.detach(), what="y")
+    close(rm_d.cpu(), rm, 1e-4, "running_mean")
+    close(rv_d.cpu(), rv, 1e-4, "running_var")
+    assert nbt.item() == 1
+    dxv = ops.new_view(N, H, H, C)
+    sums = torch.zeros(2, C, device=DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.bn_backward(to_view(dy), xv, dxv, save, gamma.to(DEV), beta.to(DEV), sums, dg, db)
+    close(from_view(dxv), xr.grad, what="dx")
+    close(dg.cpu(), g2.grad, 5e-3, "dgamma")
+    close(db.cpu(), b2.grad, 5e-3, "dbeta")
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_pool(mode):
+    N, C, H = 2, 16, 8
+    x = r(N, C, H, H, seed=20).requires_grad_(True)
+    if mode == 0:
+        y = F.max_pool2d(x, 3, 2, 1)
+    elif mode == 1:
+        y = F.max_pool2d(x, 2, 2)
+    else:
+        y = F.avg_pool2d(x, 3, 1, 1)
+    dy = r(*y.shape, seed=21)
+    y.backward(dy)
+    xv = to_view(x.detach())
+    yv = ops.new_view(N, y.shape[2], y.shape[3], C)
+    ops.pool_fwd(xv, yv, mode)
+    close(from_view(yv), y.detach(), 4e-3, "y")
+    dxv = ops.new_view(N, H, H, C, zero=True)
+    ops.pool_bwd(None if mode == 2 else xv, to_view(dy), dxv, mode)
+    close(from_view(dxv), x.grad, 1e-2, "dx")
+
+
+def test_maxpool_ties_first_max():
+    x = torch.zeros(1, 8, 4, 4)
+    y = F.max_pool2d(x.clone().requires_grad_(True), 3, 2, 1)
+    xr = x.clone().requires_grad_(True)
+    F.max_pool2d(xr, 3, 2, 1).backward(torch.ones_like(y))
+    dxv = ops.new_view(1, 4, 4, 8, zero=True)
+    ops.pool_bwd(to_view(x), to_view(torch.ones_like(y)), dxv, 0)
+    assert torch.equal(from_view(dxv), xr.grad)
+
+
+def test_upsample():
+    N, C, H = 2, 24, 4
+    x = r(N, C, H, H, seed=22).requires_grad_(True)
+    y = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    dy = r(*y.shape, seed=23)
+    y.backward(dy)
+    yv = ops.new_view(N, 2 * H, 2 * H, C)
+    ops.upsample2x_fwd(to_view(x.detach()), yv)
+    close(from_view(yv), y.detach(), 5e-3, "y")
+    dxv = ops.new_view(N, H, H, C, zero=True)
+    ops.upsample2x_bwd(to_view(dy), dxv)
+    close(from_view(dxv), x.grad, 1e-2, "dx")
+
+
+def test_softmax_fwd_bwd():
+    rows, n = 37, 256
+    S = torch.randn(rows, n, generator=torch.Generator().manual_seed(1)) * 3
+    Sr = S.clone().requires_grad_(True)
+    P = torch.softmax(Sr, -1)
+    dP = torch.randn(rows, n, generator=torch.Generator().manual_seed(2))
+    P.backward(dP)
+    Pd = torch.empty(rows, n, dtype=torch.bfloat16, device=DEV)
+    ops.softmax_fwd(S.to(DEV), Pd, rows, n)
+    close(Pd.float().cpu(), P.detach(), 5e-3, "P")
+    dS = torch.empty(rows, n, dtype=torch.bfloat16, device=DEV)
+    ops.softmax_bwd(dP.to(DEV), Pd, dS, rows, n)
+    close(dS.float().cpu(), Sr.grad, 2e-2, "dS")
+
+
+def test_adam_matches_torch():
+    n = 1003
+    p0 = torch.randn(n, generator=torch.Generator().manual_seed(3))
+    p = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([p], lr=4e-4, betas=(0.01, 0.99))
+    pd = torch.zeros(1004, device=DEV)[:n]
+    pd.copy_(p0)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        g = torch.randn(n, generator=torch.Generator().manual_seed(10 + step))
+        p.grad = g.clone()
+        opt.step()
+        ops.adam(pd, g.to(DEV), m, v, 4e-4, step)
+        assert torch.allclose(pd.cpu(), p.detach(), rtol=2e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("cout,stride", [(32, 2), (64, 1)])
+def test_conv_c1(cout, stride):
+    N, H = 3, 16
+    x = torch.randn(N, 1, H, H, generator=torch.Generator().manual_seed(4)) * 500 - 400
+    w = r(cout, 1, 3, 3, seed=24).requires_grad_(True)
+    b = r(cout, seed=25)
+    sigma = torch.tensor([1.7])
+    xa = x / 4096.0 + 0.25
+    y = F.leaky_relu(F.conv2d(xa, w / sigma, b, stride, 1), 0.2)
+    Ho = y.shape[-1]
+    yv = ops.new_view(N, Ho, Ho, cout)
+    stats = torch.zeros(2, cout, device=DEV)
+    ops.conv_c1_fwd(x.to(DEV), w.detach().to(DEV), yv, stride, sigma=sigma.to(DEV), bias=b.to(DEV),
+                    in_scale=1 / 4096.0, in_shift=0.25, act=2, stats=stats)
+    close(from_view(yv), y.detach(), what="y")
+    raw = F.conv2d(xa, w.detach() / sigma, None, stride, 1)
+    close(stats[0].cpu(), raw.sum((0, 2, 3)), 1e-3, "sum")
+    dy = r(*y.shape, seed=26)
+    raw2 = F.conv2d(xa, w, None, stride, 1)
+    (gw,) = torch.autograd.grad(raw2, w, dy)
+    dw = torch.zeros(cout, 9, device=DEV)
+    ops.conv_c1_wgrad(x.to(DEV), to_view(dy), stride, dw, in_scale=1 / 4096.0, in_shift=0.25)
+    close(dw.cpu().reshape(cout, 1, 3, 3), gw, 3e-3, "dw")
+    if stride == 1:
+        xr = xa.clone().requires_grad_(True)
+        (gx,) = torch.autograd.grad(F.conv2d(xr, w.detach() / sigma, None, 1, 1), xr, dy)
+        dx = torch.ones(N, 1, H, H, device=DEV)
+        ops.conv_c1_dgrad(to_view(dy), w.detach().to(DEV), dx, sigma=sigma.to(DEV), scale=0.5, accumulate=True)
+        close(dx.cpu() - 1.0, 0.5 * gx, 3e-3, "dx")
+
+
+def test_out_conv():
+    N, H = 2, 16
+    x = torch.randn(N, 1, H, H, generator=torch.Generator().manual_seed(5)) * 500
+    h = r(N, 32, H, H, seed=27).abs()
+    w = r(1, 33, 1, 1, seed=28).requires_grad_(True)
+    hr = h.clone().requires_grad_(True)
+    out = F.conv2d(torch.cat([x, hr], 1), w)
+    dout = torch.randn(N, 1, H, H, generator=torch.Generator().manual_seed(6))
+    out.backward(dout)
+    od = torch.empty(N, 1, H, H, device=DEV)
+    hv = to_view(h)
+    ops.out_conv_fwd(x.to(DEV), hv, w.detach().reshape(33).to(DEV), od)
+    close(od.cpu(), out.detach(), 1e-5, "out")
+    dh = ops.new_view(N, H, H, 32)
+    dw = torch.zeros(33, device=DEV)
+    ops.out_conv_bwd(x.to(DEV), hv, w.detach().reshape(33).to(DEV), dout.to(DEV), dh, dw)
+    close(from_view(dh), hr.grad, what="dh")
+    close(dw.cpu(), w.grad.reshape(33), 1e-4, "dw")
+
+
+def test_spectral_norm_sigma_and_backward():
+    R, K = 128, 576
+    Wm = torch.randn(R, K, generator=torch.Generator().manual_seed(7)) * 0.05
+    u = F.normalize(torch.randn(R, generator=torch.Generator().manual_seed(8)), dim=0)
+    v = F.normalize(torch.randn(K, generator=torch.Generator().manual_seed(9)), dim=0)
+    v1 = F.normalize(Wm.t() @ u, dim=0, eps=1e-12)
+    u1 = F.normalize(Wm @ v1, dim=0, eps=1e-12)
+    Wr = Wm.clone().requires_grad_(True)
+    sigma = torch.dot(u1, Wr @ v1)
+    Wsn = Wr / sigma
+    dWsn = torch.randn(R, K, generator=torch.Generator().manual_seed(10))
+    Wsn.backward(dWsn)
+    ud, vd = u.to(DEV), v.to(DEV)
+    sg = torch.zeros(1, device=DEV)
+    scratch = torch.zeros(K + R + 2, device=DEV)
+    ops.sn_sigma(Wm.to(DEV), R, K, ud, vd, sg, scratch, True)
+    close(ud.cpu(), u1, 1e-5, "u")
+    close(vd.cpu(), v1, 1e-5, "v")
+    close(sg.cpu(), sigma.detach().reshape(1), 1e-5, "sigma")
+    sg2 = torch.zeros(1, device=DEV)
+    ops.sn_sigma(Wm.to(DEV), R, K, ud, vd, sg2, scratch, False)
+    close(sg2.cpu(), sigma.detach().reshape(1), 1e-5, "sigma (no power iteration)")
+    dW = torch.zeros(R, K, device=DEV)
+    ops.sn_backward(dWsn.to(DEV), Wm.to(DEV), ud, vd, sg, R, K, dW, scratch[:1])
+    close(dW.cpu(), Wr.grad, 1e-4, "dW")
+
+
+def test_mse_tap_and_loss_scalars():
+    n = 4096 * 3
+    a, b = r(n, seed=29), r(n, seed=30)
+    loss = torch.zeros(1, device=DEV)
+    g = torch.ones(n, dtype=torch.bfloat16, device=DEV)
+    ad, bd = a.to(torch.bfloat16).to(DEV), b.to(torch.bfloat16).to(DEV)
+    ops.mse_tap(ad.data_ptr(), bd.data_ptr(), n, 1.0 / n, loss, g.data_ptr(), 0.25, accumulate=True)
+    close(loss.cpu(), ((a - b) ** 2).mean().reshape(1), 1e-4, "mse")
+    close(g.float().cpu(), 1.0 + 0.25 * (a - b), what="grad")
+    sc = torch.zeros(16, device=DEV)
+    sc[0], sc[1], sc[5], sc[6] = 0.3, -2.0, 0.7, 0.4
+    ops.dloss_scalars(sc, 1000)
+    ops.gloss_scalars(sc, 0.3, 0.5, 0.2)
+    s = sc.cpu()
+    assert abs(s[2] - 0.7) < 1e-6 and abs(s[3] + 1e-3) < 1e-9 and s[4] == 0
+    assert abs(s[7] - 0.3) < 1e-6 and abs(s[8] - 3.0) < 1e-6 and abs(s[9] - (0.21 + 0.15 + 0.6)) < 1e-6
+
+
+def test_misc_elementwise():
+    N, C, H = 2, 32, 4
+    a, y = r(N, C, H, H, seed=31), r(N, C, H, H, seed=32)
+    av, yv = to_view(a), to_view(y)
+    o = ops.new_view(N, H, H, C, zero=True)
+    ops.ew(ops.EW_ACTBWD, av, o, y=yv, slope=0.2)
+    close(from_view(o), a * torch.where(y > 0, 1.0, 0.2), what="actbwd")
+    ops.ew(ops.EW_ADD, av, o)
+    close(from_view(o), a * torch.where(y > 0, 1.0, 0.2) + a, what="add")
+    s = torch.tensor([0.7], device=DEV)
+    ops.ew(ops.EW_AXPY, av, o, y=yv, s=s)
+    close(from_view(o), 0.7 * a + y, what="axpy")
+    cs = torch.zeros(C, device=DEV)
+    ops.colsum(av, cs)
+    close(cs.cpu(), a.sum((0, 2, 3)), 1e-3, "colsum")
+    d = torch.zeros(1, device=DEV)
+    ops.dot(av, yv, 0.5, d)
+    close(d.cpu(), (0.5 * (a * y).sum()).reshape(1), 1e-3, "dot")
+    ops.fill(o, 2.0, s=s)
+    close(from_view(o), torch.full((N, C, H, H), 1.4), 5e-3, "fill")
+    x32 = torch.randn(N, C, H, H, generator=torch.Generator().manual_seed(11))
+    ops.nchw_to_nhwc(x32.to(DEV), o)
+    close(from_view(o), x32, 5e-3, "nchw->nhwc")
+    back = torch.empty(N, C, H, H, device=DEV)
+    ops.nhwc_to_nchw(o, back)
+    close(back.cpu(), from_view(o), 1e-7, "nhwc->nchw")
+
+
+def _ssim_ref(a, b, c1, c2):
+    from oracle import ried_oracle as O
+    return O.ssim_map(a, b, c1, c2)
+
+
+@pytest.mark.parametrize("H,W", [(64, 64), (40, 72), (512, 512)])
+def test_ssim_forward_backward(H, W):
+    N = 2
+    g = torch.Generator().manual_seed(12)
+    ref = (torch.randn(N, 1, H, W, generator=g) * 520 - 470).clamp(-1024, 3072)
+    a = (ref + torch.randn(N, 1, H, W, generator=g) * 30).clamp(-1024, 3072)
+    ar = a.clone().requires_grad_(True)
+    m = _ssim_ref(ref, ar, 1e-4, 9e-4)
+    m.sum().backward()
+    sums = torch.zeros(N, 4, device=DEV)
+    gmap = torch.empty(3, N, H, W, device=DEV)
+    ops.ssim_fwd(a.to(DEV), None, ref.to(DEV), 1e-4, 9e-4, sums, gmap=gmap)
+    close(sums[:, 0].cpu(), m.detach().sum((1, 2, 3)), 2e-4, "ssim sum")
+    close(sums[:, 1].cpu(), ((a - ref) ** 2).sum((1, 2, 3)), 1e-5, "sq err")
+    da = torch.zeros(N, 1, H, W, device=DEV)
+    ops.ssim_bwd(a.to(DEV), ref.to(DEV), gmap, 1.0, da)
+    close(da.cpu(), ar.grad, 2e-3, "d ssim / d a")
+
+
+def test_metrics_three_image_form():
+    from oracle import ried_oracle as O
+    N, H = 2, 128
+    g = torch.Generator().manual_seed(13)
+    y = torch.randn(N, 1, H, H, generator=g) * 520 - 470
+    x = y + torch.randn(N, 1, H, H, generator=g) * 30
+    p = y + torch.randn(N, 1, H, H, generator=g) * 10
+    sums = torch.zeros(N, 4, device=DEV)
+    ops.ssim_fwd(x.to(DEV), p.to(DEV), y.to(DEV), 16.0, 144.0, sums, clamp=(-160.0, 240.0))
+    s = sums.cpu() / (H * H)
+    for i in range(N):
+        xi, yi, pi = [O.trunc(t[i, 0]) for t in (x, y, p)]
+        o, q = O.compute_measure(xi, yi, pi, 400.0)
+        assert abs(s[i, 0] - o[1]) < 2e-5 and abs(s[i, 2] - q[1]) < 2e-5
+        assert abs(s[i, 1].sqrt() - o[2]) < 1e-3 * o[2] and abs(s[i, 3].sqrt() - q[2]) < 1e-3 * q[2]
