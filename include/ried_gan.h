@@ -36,10 +36,12 @@ int ried_device_cus(void);
  *   x: view [nimg][H][W] with Cin channels; w: packed bf16 [Cout][kh][kw][Cin]; y: view [nimg][Ho][Wo], Cout.
  *   bias: fp32 [Cout] or NULL; act: 0 none, 1 ReLU, 2 LeakyReLU(0.2); stats: fp32 [2][Cout] accumulated with the
  *   per-channel sum and sum of squares of the fp32 results (for train-mode BatchNorm) or NULL;
- *   accumulate: y += result; out_f32: y is fp32 instead of bf16. */
+ *   accumulate: y += result; out_f32: y is fp32 instead of bf16; y2/ldy2: optional second, fp32 copy of the
+ *   result (the perceptual-loss taps are compared in fp32) or NULL. */
 int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W, int Cin,
                 int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
-                const float* bias, int act, float* stats, int accumulate, int out_f32, ried_stream_t stream);
+                const float* bias, int act, float* stats, int accumulate, int out_f32, float* y2, long long ldy2,
+                ried_stream_t stream);
 
 /* Weight-gradient partial sums (autograd of the convs above).  g is the tensor seen through the kernel window
  * (Conv2d: the layer input; ConvTranspose2d: the output gradient), p the tensor indexed by output pixel.
@@ -106,9 +108,12 @@ int ried_softmax_bwd(const float* dP, const void* P, void* dS, long long rows, i
 int ried_nchw_to_nhwc(const float* x, void* y, long long ldy, int nimg, int C, long long HW, ried_stream_t stream);
 int ried_nhwc_to_nchw(const void* x, long long ldx, float* y, int nimg, int C, long long HW, ried_stream_t stream);
 
-/* torch.optim.Adam step over a flat fp32 buffer (src/train.py:104-105,165,177); step >= 1 is the host's counter. */
+/* torch.optim.Adam step over a flat fp32 buffer (src/train.py:104-105,165,177).  step: device int32 counter of
+ * completed steps, incremented by this call before use (so a captured graph replays correctly). */
 int ried_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
-              int step, ried_stream_t stream);
+              int* step, ried_stream_t stream);
+/* out[0] += scale * sum_i in[i*stride], i < n  (fp32) */
+int ried_sum_f32(const float* in, long long n, long long stride, float scale, float* out, ried_stream_t stream);
 
 /* ---- one-input-channel 3x3 pad-1 convolutions on the fp32 image ----------------------------------------------- */
 /* generator conv1 (src/rinet.py:55), discriminator layer 0 (:20), VGG16 layer 0 on cat([x,x,x]) (src/loss.py:181)
@@ -138,7 +143,8 @@ int ried_sn_backward(const float* dWsn, const float* Wm, const float* u, const f
                      int K, float* dW, float* scratch1, int accumulate, ried_stream_t stream);
 
 /* ---- losses ---------------------------------------------------------------------------------------------------- */
-/* nn.MSELoss on one VGG tap (src/loss.py:185-187): loss[0] += loss_scale*sum (a-b)^2; g (+)= grad_scale*(a-b) */
+/* nn.MSELoss on one VGG tap (src/loss.py:185-187): a, b fp32 [n]; loss[0] += loss_scale*sum (a-b)^2;
+ * g (bf16 [n]) (+)= grad_scale*(a-b) */
 int ried_mse_tap(const void* a, const void* b, long long n, float loss_scale, float* loss, void* g, float grad_scale,
                  int accumulate, ried_stream_t stream);
 /* DLoss (src/loss.py:141-142): sc[0]=mean(pos), sc[1]=mean(neg) -> sc[2]=loss, sc[3], sc[4] = per-element gradients */

@@ -33,6 +33,25 @@ import torch
 import torch.nn.functional as F
 
 Tensor = torch.Tensor
+
+# ---------------------------------------------------------------------------
+# optional emulation of the product's storage precision: with EMULATE_BF16 set, every tensor the HIP path keeps
+# in bf16 (packed weights, pre-BN conv outputs, activations, attention probabilities) is rounded to bf16 at the
+# same point, while all arithmetic stays fp32 as in the MFMA accumulators.  Off by default: the plain oracle is
+# the fp32 reference arithmetic.  Tests use both: tight tolerance against the emulation, loose against fp32.
+# ---------------------------------------------------------------------------
+EMULATE_BF16 = False
+
+
+def set_bf16_emulation(flag: bool) -> None:
+    global EMULATE_BF16
+    EMULATE_BF16 = bool(flag)
+
+
+def _r(t: Tensor) -> Tensor:
+    return t.to(torch.bfloat16).to(torch.float32) if EMULATE_BF16 else t
+
+
 BN_EPS = 1e-5          # nn.BatchNorm2d default; eps=0.001 is commented out (rinet.py:187,199)
 BN_MOMENTUM = 0.1
 SN_EPS = 1e-12         # torch.nn.utils.spectral_norm default
@@ -79,7 +98,8 @@ def _pair(v):
     return (v, v) if isinstance(v, int) else tuple(v)
 
 
-def _bn_relu(P: Params, pre: str, x: Tensor, c: int, training: bool, relu: bool = True) -> Tensor:
+def _bn_relu(P: Params, pre: str, x: Tensor, c: int, training: bool, relu: bool = True,
+             round_out: bool = True) -> Tensor:
     """BatchNorm2d (+ReLU).  Train mode uses batch statistics and updates the
     running stats with momentum 0.1 and the unbiased variance (torch semantics;
     rinet.py:187-193)."""
@@ -97,19 +117,27 @@ def _bn_relu(P: Params, pre: str, x: Tensor, c: int, training: bool, relu: bool 
         P.set(pre + ".running_mean", (1 - BN_MOMENTUM) * rm + BN_MOMENTUM * mean)
         P.set(pre + ".running_var", (1 - BN_MOMENTUM) * rv + BN_MOMENTUM * var_u)
         P.set(pre + ".num_batches_tracked", nbt + 1)
-        y = F.batch_norm(x, None, None, w, b, True, BN_MOMENTUM, BN_EPS)
+        if EMULATE_BF16:   # statistics from the fp32 accumulators, normalisation of the bf16-stored conv output
+            m_g = x.mean(dim=(0, 2, 3))                                  # attached: gradients flow through the stats
+            istd = torch.rsqrt(x.var(dim=(0, 2, 3), unbiased=False) + BN_EPS)
+            y = (_r(x) - m_g.view(1, -1, 1, 1)) * (w * istd).view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+        else:
+            y = F.batch_norm(x, None, None, w, b, True, BN_MOMENTUM, BN_EPS)
     else:
-        y = F.batch_norm(x, rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
-    return F.relu(y) if relu else y
+        y = F.batch_norm(_r(x), rm, rv, w, b, False, BN_MOMENTUM, BN_EPS)
+    y = F.relu(y) if relu else y
+    return _r(y) if round_out else y      # a branch that is added onto the residual is rounded after the add
 
 
 def basic_conv(P: Params, pre: str, x: Tensor, cin: int, cout: int, k, stride=1, pad=0,
-               training: bool = True) -> Tensor:
+               training: bool = True, final: bool = False) -> Tensor:
     """BasicConv2d: conv(no bias) -> BN -> ReLU (rinet.py:183-193)."""
     kh, kw = _pair(k)
     w = P.get(pre + ".conv.weight", (cout, cin, kh, kw))
+    if cin > 1:          # the one-channel first layer runs in fp32 on the raw image
+        w = _r(w)
     y = F.conv2d(x, w, None, stride, _pair(pad))
-    return _bn_relu(P, pre + ".bn", y, cout, training)
+    return _bn_relu(P, pre + ".bn", y, cout, training, round_out=not final)
 
 
 def basic_deconv(P: Params, pre: str, x: Tensor, cin: int, cout: int, k, stride=1, pad=0,
@@ -117,7 +145,7 @@ def basic_deconv(P: Params, pre: str, x: Tensor, cin: int, cout: int, k, stride=
     """BasicDeconv2d: ConvTranspose2d(no bias) -> BN -> ReLU (rinet.py:195-205).
     The weight is laid out (Cin, Cout, kh, kw)."""
     kh, kw = _pair(k)
-    w = P.get(pre + ".deconv.weight", (cin, cout, kh, kw))
+    w = _r(P.get(pre + ".deconv.weight", (cin, cout, kh, kw)))
     y = F.conv_transpose2d(x, w, None, stride, _pair(pad))
     return _bn_relu(P, pre + ".bn", y, cout, training)
 
@@ -126,7 +154,7 @@ def _identity_path(P: Params, pre: str, x: Tensor, cin: int, cout: int, has_ds: 
     """identity_downsample = Conv1x1(no bias) + BN + ReLU (rinet.py:98-103)."""
     if not has_ds:
         return x
-    w = P.get(pre + ".identity_downsample.0.weight", (cout, cin, 1, 1))
+    w = _r(P.get(pre + ".identity_downsample.0.weight", (cout, cin, 1, 1)))
     y = F.conv2d(x, w)
     return _bn_relu(P, pre + ".identity_downsample.1", y, cout, training)
 
@@ -134,16 +162,16 @@ def _identity_path(P: Params, pre: str, x: Tensor, cin: int, cout: int, has_ds: 
 def inception_a(P: Params, pre: str, x: Tensor, cin: int, has_ds: bool, training: bool = True) -> Tensor:
     """rinet.py:207-252 -> 32|32|48|16 = 128 channels, plus identity, no activation after the sum."""
     t = training
-    b1 = basic_conv(P, pre + ".branch1x1", x, cin, 32, 1, training=t)
+    b1 = basic_conv(P, pre + ".branch1x1", x, cin, 32, 1, training=t, final=True)
     b3 = basic_conv(P, pre + ".branch3x3_1", x, cin, 16, 1, training=t)
-    b3 = basic_conv(P, pre + ".branch3x3_2", b3, 16, 32, 3, pad=1, training=t)
+    b3 = basic_conv(P, pre + ".branch3x3_2", b3, 16, 32, 3, pad=1, training=t, final=True)
     bd = basic_conv(P, pre + ".branch3x3dbl_1", x, cin, 32, 1, training=t)
     bd = basic_conv(P, pre + ".branch3x3dbl_2", bd, 32, 48, 3, pad=1, training=t)
-    bd = basic_conv(P, pre + ".branch3x3dbl_3", bd, 48, 48, 3, pad=1, training=t)
-    bp = F.avg_pool2d(x, 3, 1, 1)
-    bp = basic_conv(P, pre + ".branch_pool", bp, cin, 16, 1, training=t)
+    bd = basic_conv(P, pre + ".branch3x3dbl_3", bd, 48, 48, 3, pad=1, training=t, final=True)
+    bp = _r(F.avg_pool2d(x, 3, 1, 1))
+    bp = basic_conv(P, pre + ".branch_pool", bp, cin, 16, 1, training=t, final=True)
     out = torch.cat([b1, b3, bd, bp], 1)
-    return out + _identity_path(P, pre, x, cin, 128, has_ds, t)
+    return _r(out + _identity_path(P, pre, x, cin, 128, has_ds, t))
 
 
 def inception_b(P: Params, pre: str, x: Tensor, cin: int, decoder: bool, training: bool = True) -> Tensor:
@@ -159,8 +187,8 @@ def inception_b(P: Params, pre: str, x: Tensor, cin: int, decoder: bool, trainin
     bd = blk(P, pre + ".branch3x3dbl_2", bd, 32, 48, 3, pad=1, training=t)
     bd = blk(P, pre + ".branch3x3dbl_3", bd, 48, 64, k, stride=2, pad=1, training=t)
     if decoder:
-        w = P.get(pre + ".sample.0.weight", (128, cin, 1, 1))
-        bp = F.interpolate(F.conv2d(x, w), scale_factor=2, mode="bilinear", align_corners=True)
+        w = _r(P.get(pre + ".sample.0.weight", (128, cin, 1, 1)))
+        bp = _r(F.interpolate(_r(F.conv2d(x, w)), scale_factor=2, mode="bilinear", align_corners=True))
     else:
         bp = F.max_pool2d(x, 3, 2, 1)
     return torch.cat([b3, bd, bp], 1)
@@ -169,19 +197,19 @@ def inception_b(P: Params, pre: str, x: Tensor, cin: int, decoder: bool, trainin
 def inception_c(P: Params, pre: str, x: Tensor, cin: int, c7: int, has_ds: bool, training: bool = True) -> Tensor:
     """rinet.py:293-347 -> 4 x 64 = 256 channels plus identity."""
     t = training
-    b1 = basic_conv(P, pre + ".branch1x1", x, cin, 64, 1, training=t)
+    b1 = basic_conv(P, pre + ".branch1x1", x, cin, 64, 1, training=t, final=True)
     b7 = basic_conv(P, pre + ".branch7x7_1", x, cin, c7, 1, training=t)
     b7 = basic_conv(P, pre + ".branch7x7_2", b7, c7, c7, (1, 7), pad=(0, 3), training=t)
-    b7 = basic_conv(P, pre + ".branch7x7_3", b7, c7, 64, (7, 1), pad=(3, 0), training=t)
+    b7 = basic_conv(P, pre + ".branch7x7_3", b7, c7, 64, (7, 1), pad=(3, 0), training=t, final=True)
     bd = basic_conv(P, pre + ".branch7x7dbl_1", x, cin, c7, 1, training=t)
     bd = basic_conv(P, pre + ".branch7x7dbl_2", bd, c7, c7, (7, 1), pad=(3, 0), training=t)
     bd = basic_conv(P, pre + ".branch7x7dbl_3", bd, c7, c7, (1, 7), pad=(0, 3), training=t)
     bd = basic_conv(P, pre + ".branch7x7dbl_4", bd, c7, c7, (7, 1), pad=(3, 0), training=t)
-    bd = basic_conv(P, pre + ".branch7x7dbl_5", bd, c7, 64, (1, 7), pad=(0, 3), training=t)
-    bp = F.avg_pool2d(x, 3, 1, 1)
-    bp = basic_conv(P, pre + ".branch_pool", bp, cin, 64, 1, training=t)
+    bd = basic_conv(P, pre + ".branch7x7dbl_5", bd, c7, 64, (1, 7), pad=(0, 3), training=t, final=True)
+    bp = _r(F.avg_pool2d(x, 3, 1, 1))
+    bp = basic_conv(P, pre + ".branch_pool", bp, cin, 64, 1, training=t, final=True)
     out = torch.cat([b1, b7, bd, bp], 1)
-    return out + _identity_path(P, pre, x, cin, 256, has_ds, t)
+    return _r(out + _identity_path(P, pre, x, cin, 256, has_ds, t))
 
 
 def inception_d(P: Params, pre: str, x: Tensor, cin: int, decoder: bool, training: bool = True) -> Tensor:
@@ -196,8 +224,8 @@ def inception_d(P: Params, pre: str, x: Tensor, cin: int, decoder: bool, trainin
     b7 = blk(P, pre + ".branch7x7x3_3", b7, 128, 128, (7, 1), pad=(3, 0), training=t)
     b7 = blk(P, pre + ".branch7x7x3_4", b7, 128, 128, k, stride=2, pad=1, training=t)
     if decoder:
-        w = P.get(pre + ".sample.0.weight", (256, cin, 1, 1))
-        bp = F.interpolate(F.conv2d(x, w), scale_factor=2, mode="bilinear", align_corners=True)
+        w = _r(P.get(pre + ".sample.0.weight", (256, cin, 1, 1)))
+        bp = _r(F.interpolate(_r(F.conv2d(x, w)), scale_factor=2, mode="bilinear", align_corners=True))
     else:
         bp = F.max_pool2d(x, 3, 2, 1)
     return torch.cat([b3, b7, bp], 1)
@@ -206,18 +234,18 @@ def inception_d(P: Params, pre: str, x: Tensor, cin: int, decoder: bool, trainin
 def inception_e(P: Params, pre: str, x: Tensor, cin: int, has_ds: bool, training: bool = True) -> Tensor:
     """rinet.py:389-445 -> 160 | 192+192 | 192+192 | 96 = 1024 channels plus identity."""
     t = training
-    b1 = basic_conv(P, pre + ".branch1x1", x, cin, 160, 1, training=t)
+    b1 = basic_conv(P, pre + ".branch1x1", x, cin, 160, 1, training=t, final=True)
     b3 = basic_conv(P, pre + ".branch3x3_1", x, cin, 192, 1, training=t)
-    b3a = basic_conv(P, pre + ".branch3x3_2a", b3, 192, 192, (1, 3), pad=(0, 1), training=t)
-    b3b = basic_conv(P, pre + ".branch3x3_2b", b3, 192, 192, (3, 1), pad=(1, 0), training=t)
+    b3a = basic_conv(P, pre + ".branch3x3_2a", b3, 192, 192, (1, 3), pad=(0, 1), training=t, final=True)
+    b3b = basic_conv(P, pre + ".branch3x3_2b", b3, 192, 192, (3, 1), pad=(1, 0), training=t, final=True)
     bd = basic_conv(P, pre + ".branch3x3dbl_1", x, cin, 224, 1, training=t)
     bd = basic_conv(P, pre + ".branch3x3dbl_2", bd, 224, 192, 3, pad=1, training=t)
-    bda = basic_conv(P, pre + ".branch3x3dbl_3a", bd, 192, 192, (1, 3), pad=(0, 1), training=t)
-    bdb = basic_conv(P, pre + ".branch3x3dbl_3b", bd, 192, 192, (3, 1), pad=(1, 0), training=t)
-    bp = F.avg_pool2d(x, 3, 1, 1)
-    bp = basic_conv(P, pre + ".branch_pool", bp, cin, 96, 1, training=t)
+    bda = basic_conv(P, pre + ".branch3x3dbl_3a", bd, 192, 192, (1, 3), pad=(0, 1), training=t, final=True)
+    bdb = basic_conv(P, pre + ".branch3x3dbl_3b", bd, 192, 192, (3, 1), pad=(1, 0), training=t, final=True)
+    bp = _r(F.avg_pool2d(x, 3, 1, 1))
+    bp = basic_conv(P, pre + ".branch_pool", bp, cin, 96, 1, training=t, final=True)
     out = torch.cat([b1, b3a, b3b, bda, bdb, bp], 1)
-    return out + _identity_path(P, pre, x, cin, 1024, has_ds, t)
+    return _r(out + _identity_path(P, pre, x, cin, 1024, has_ds, t))
 
 
 G_TOP_ACTS = ["conv1", "conv2", "layer_block_1", "reduce_grid_1", "layer_block_2", "reduce_grid_2",
@@ -281,8 +309,10 @@ def sn_weight(P: Params, pre: str, cout: int, cin: int, k: int, training: bool) 
 def sn_conv(P: Params, pre: str, x: Tensor, cin: int, cout: int, stride: int, training: bool) -> Tensor:
     """SNConv2d: SN conv 3x3 pad 1 with bias, LeakyReLU(0.2) (rinet.py:131-148)."""
     w = sn_weight(P, pre + ".conv2d", cout, cin, 3, training)
+    if cin > 1:
+        w = _r(w)
     b = P.get(pre + ".conv2d.bias", (cout,))
-    return F.leaky_relu(F.conv2d(x, w, b, stride, 1), 0.2)
+    return _r(F.leaky_relu(F.conv2d(x, w, b, stride, 1), 0.2))
 
 
 def self_attn(P: Params, pre: str, x: Tensor, c: int) -> Tensor:
@@ -293,12 +323,12 @@ def self_attn(P: Params, pre: str, x: Tensor, c: int) -> Tensor:
     wk = P.get(pre + ".key_conv.weight", (c // 8, c, 1, 1)); bk = P.get(pre + ".key_conv.bias", (c // 8,))
     wv = P.get(pre + ".value_conv.weight", (c, c, 1, 1)); bv = P.get(pre + ".value_conv.bias", (c,))
     gamma = P.get(pre + ".gamma", (1,))
-    q = F.conv2d(x, wq, bq).view(B, -1, n).permute(0, 2, 1)      # B x N x d
-    k = F.conv2d(x, wk, bk).view(B, -1, n)                       # B x d x N
-    att = torch.softmax(torch.bmm(q, k), dim=-1)                 # B x N x N
-    v = F.conv2d(x, wv, bv).view(B, -1, n)                       # B x C x N
-    out = torch.bmm(v, att.permute(0, 2, 1)).view(B, C, H, W)
-    return gamma * out + x
+    q = _r(F.conv2d(x, _r(wq), bq)).view(B, -1, n).permute(0, 2, 1)      # B x N x d
+    k = _r(F.conv2d(x, _r(wk), bk)).view(B, -1, n)                       # B x d x N
+    att = _r(torch.softmax(torch.bmm(q, k), dim=-1))                     # B x N x N
+    v = _r(F.conv2d(x, _r(wv), bv)).view(B, -1, n)                       # B x C x N
+    out = _r(torch.bmm(v, att.permute(0, 2, 1))).view(B, C, H, W)
+    return _r(gamma * out + x)
 
 
 def discriminator_forward(P: Params, x: Tensor, training: bool = True,
@@ -432,10 +462,12 @@ def vgg_taps(vgg: Dict[str, Tensor], x3: Tensor) -> List[Tensor]:
             h = F.max_pool2d(h, 2, 2)
             idx += 1
         else:
-            h = F.relu(F.conv2d(h, vgg[f"{idx}.weight"], vgg[f"{idx}.bias"], 1, 1))
+            w = vgg[f"{idx}.weight"] if idx == 0 else _r(vgg[f"{idx}.weight"])
+            h = F.relu(F.conv2d(h, w, vgg[f"{idx}.bias"], 1, 1))
             idx += 2
             if idx - 1 in VGG_TAPS:
-                feats.append(h)
+                feats.append(h)          # taps are compared in fp32
+            h = _r(h)
     return feats
 
 
@@ -534,6 +566,10 @@ def train_step(st: TrainState, x: Tensor, y: Tensor, want_grads: bool = False) -
         if last:
             gl, vl, sl, genl = compound_loss(st.vgg, pred, y, neg)
             gnames = [k for k in gp if trainable(k)]
+            if want_grads:      # d gloss / d pred and its three parts (diagnostics for the tests)
+                for nm, term in (("dpred_vgg", 0.3 * vl), ("dpred_dssim", 0.5 * sl), ("dpred_gen", 0.2 * genl)):
+                    out[nm] = torch.autograd.grad(term, pred, retain_graph=True)[0].detach()
+                out["dpred"] = out["dpred_vgg"] + out["dpred_dssim"] + out["dpred_gen"]
             g_grads = dict(zip(gnames, torch.autograd.grad(gl, [gp[k] for k in gnames])))
             out.update(gloss=gl.item(), vgg=vl.item(), dssim=sl.item(), gen=genl.item())
         st.d_step += 1

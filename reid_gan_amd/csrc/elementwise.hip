@@ -180,11 +180,11 @@ __global__ void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, long long ld
   __syncthreads();
   const int CC = C >> 3;
   // a thread keeps the same channel chunk across its loop when the stride is a multiple of CC
-  long long stride = (long long)gridDim.x * blockDim.x;
-  stride = (stride + CC - 1) / CC * CC;
+  // (threads beyond the largest multiple of CC stay idle so no element is skipped)
+  long long stride = (long long)gridDim.x * blockDim.x / CC * CC;
   long long total = npix * CC;
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i < total) {
+  if (i < total && i < stride) {
     int c = (int)(i % CC) << 3;
     float a[8], b[8], mean[8], istd[8], s1[8], s2[8];
 #pragma unroll
@@ -259,6 +259,7 @@ extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, l
   RIED_CHECK_ARG(save && gamma && beta && sums && npix > 0, "ried_bn_backward: bad arguments");
   RIED_CHECK_ARG(C <= 4096, "ried_bn_backward: C too large");
   int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, 1024);
+  if (grid * EW_THREADS < C / 8) grid = ceil_div(C / 8, EW_THREADS);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), 2 * C * sizeof(float), stream,
                      (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, sums);
   if (dgamma && dbeta)
@@ -582,11 +583,11 @@ __global__ void colsum_kernel(const bf16_t* __restrict__ a, long long lda, long 
   for (int i = threadIdx.x; i < C; i += blockDim.x) lsum[i] = 0.f;
   __syncthreads();
   const int CC = C >> 3;
-  long long stride = (long long)gridDim.x * blockDim.x;
-  stride = (stride + CC - 1) / CC * CC;
+  // (threads beyond the largest multiple of CC stay idle so no element is skipped)
+  long long stride = (long long)gridDim.x * blockDim.x / CC * CC;
   long long total = npix * CC;
   long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i < total) {
+  if (i < total && i < stride) {
     int c = (int)(i % CC) << 3;
     float s[8];
 #pragma unroll
@@ -608,7 +609,9 @@ __global__ void colsum_kernel(const bf16_t* __restrict__ a, long long lda, long 
 extern "C" int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, hipStream_t stream) {
   CHECK_VIEW("ried_colsum", a, lda, C);
   RIED_CHECK_ARG(out && npix > 0 && C <= 8192, "ried_colsum: bad arguments");
-  hipLaunchKernelGGL(colsum_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS * 8, 512)), dim3(EW_THREADS),
+  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, 512);
+  if (grid * EW_THREADS < C / 8) grid = ceil_div(C / 8, EW_THREADS);
+  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(EW_THREADS),
                      C * sizeof(float), stream, (const bf16_t*)a, lda, npix, C, out);
   RIED_CHECK_LAUNCH("ried_colsum");
   return RIED_OK;
@@ -704,12 +707,17 @@ extern "C" int ried_dot(const void* a, long long lda, const void* b, long long l
 
 // ---------------------------------------------------------------------------
 // fused Adam over a flat fp32 parameter buffer (torch.optim.Adam defaults; reference: src/train.py:104-105)
-// step_count is a device int32 incremented by this kernel's first thread AFTER use is not safe across blocks,
-// so the bias corrections are passed by the host, which owns the step counter.
 // ---------------------------------------------------------------------------
+__global__ void adam_tick_kernel(int* step) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1;
+}
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float bc1,
-                            float bc2_sqrt) {
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                            const int* __restrict__ step) {
+  const float st = (float)step[0];
+  const float bc1 = 1.f - powf(b1, st);
+  const float bc2_sqrt = sqrtf(1.f - powf(b2, st));
+  const float a = lr / bc1;
   for (long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4; i < n;
        i += (long long)gridDim.x * blockDim.x * 4) {
     if (i + 4 <= n) {
@@ -720,7 +728,7 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         mm[q] = b1 * mm[q] + (1.f - b1) * gg[q];
         vv[q] = b2 * vv[q] + (1.f - b2) * gg[q] * gg[q];
         float denom = sqrtf(vv[q]) / bc2_sqrt + eps;
-        pp[q] -= (lr / bc1) * (mm[q] / denom);
+        pp[q] -= a * (mm[q] / denom);
       }
       *reinterpret_cast<f32x4*>(p + i) = pp;
       *reinterpret_cast<f32x4*>(m + i) = mm;
@@ -730,20 +738,22 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
         float mj = b1 * m[j] + (1.f - b1) * g[j];
         float vj = b2 * v[j] + (1.f - b2) * g[j] * g[j];
         m[j] = mj; v[j] = vj;
-        p[j] -= (lr / bc1) * (mj / (sqrtf(vj) / bc2_sqrt + eps));
+        p[j] -= a * (mj / (sqrtf(vj) / bc2_sqrt + eps));
       }
     }
   }
 }
 
+// step: device int32 counter of completed steps; it is incremented first, then used for the bias corrections,
+// so a captured HIP graph replays with the right step number.
 extern "C" int ried_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2,
-                         float eps, int step, hipStream_t stream) {
-  RIED_CHECK_ARG(p && g && m && v && n > 0 && step >= 1, "ried_adam: bad arguments");
+                         float eps, int* step, hipStream_t stream) {
+  RIED_CHECK_ARG(p && g && m && v && step && n > 0, "ried_adam: bad arguments");
   RIED_CHECK_ARG(((uintptr_t)p % 16) == 0 && ((uintptr_t)g % 16) == 0 && ((uintptr_t)m % 16) == 0 &&
                      ((uintptr_t)v % 16) == 0, "ried_adam: buffers must be 16-byte aligned");
-  double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+  hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(64), 0, stream, step);
   hipLaunchKernelGGL(adam_kernel, dim3(ew_grid(n, EW_THREADS * 4, 2048)), dim3(EW_THREADS), 0, stream, p, g, m, v, n,
-                     lr, b1, b2, eps, (float)bc1, (float)sqrt(bc2));
+                     lr, b1, b2, eps, step);
   RIED_CHECK_LAUNCH("ried_adam");
   return RIED_OK;
 }

@@ -47,6 +47,8 @@ struct GemmEpilogue {
   const bf16_t* resid;
   long long ld_resid, resid_batch_stride;
   float alpha;
+  float* out2;             // optional second copy of the result in fp32 (same row mapping), or null
+  long long ldc2;
   int phase_mode, Wo_full, HoWo_full, Hq, Wq, sh, sw;   // logical row -> physical pixel
 };
 
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
         v[0] = gam * v[0] + bflo(rr[0]); v[1] = gam * v[1] + bfhi(rr[0]);
         v[2] = gam * v[2] + bflo(rr[1]); v[3] = gam * v[3] + bfhi(rr[1]);
       }
+      if (E.out2) *reinterpret_cast<f32x4*>(E.out2 + orow * E.ldc2 + m) = f32x4{v[0], v[1], v[2], v[3]};
       long long off = obase + orow * E.ldc + m;
       if (E.out_f32) {
         float* op = (float*)outb + off;
@@ -469,7 +472,7 @@ static void default_epilogue(GemmEpilogue& E) {
 extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
                            int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                            int transposed, const float* bias, int act, float* stats, int accumulate, int out_f32,
-                           hipStream_t stream) {
+                           float* y2, long long ldy2, hipStream_t stream) {
   RIED_CHECK_ARG(x && w && y, "ried_conv2d: null pointer");
   RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
   RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
@@ -508,6 +511,8 @@ extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y,
   P.M = Cout; P.N = (int)npix; P.K = Cin; P.taps = kh * kw; P.splitk = 1;
   P.E.out = y; P.E.ldc = ldy; P.E.out_f32 = out_f32; P.E.bias = bias; P.E.act = act; P.E.stats = stats;
   P.E.accumulate = accumulate;
+  RIED_CHECK_ARG(!y2 || (ldy2 % 4 == 0 && ldy2 >= Cout && ((uintptr_t)y2 % 16) == 0), "ried_conv2d: bad y2 view");
+  P.E.out2 = y2; P.E.ldc2 = ldy2;
   if (Cout <= 64) {
     P.tiles_m = ceil_div(Cout, 64);
     dim3 grid(P.tiles_m * ceil_div(npix, 128), phases, 1);

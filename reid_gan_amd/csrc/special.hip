@@ -415,19 +415,21 @@ extern "C" int ried_sn_backward(const float* dWsn, const float* Wm, const float*
 // perceptual-loss tap: loss[0] += loss_scale * sum (a-b)^2 ;  g (+)= grad_scale * (a-b)
 // a = features of the prediction, b = features of the target (src/loss.py:184-189)
 // ---------------------------------------------------------------------------
-__global__ void mse_tap_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b, long long n8,
+__global__ void mse_tap_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n8,
                                float loss_scale, float* __restrict__ loss, bf16_t* __restrict__ g, float grad_scale,
                                int accumulate) {
   __shared__ float sh[4];
   float acc = 0.f;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
-    float fa[8], fb[8], fg[8];
-    unpack8s(*reinterpret_cast<const u32x4*>(a + i * 8), fa);
-    unpack8s(*reinterpret_cast<const u32x4*>(b + i * 8), fb);
+    f32x4 a0 = *reinterpret_cast<const f32x4*>(a + i * 8), a1 = *reinterpret_cast<const f32x4*>(a + i * 8 + 4);
+    f32x4 b0 = *reinterpret_cast<const f32x4*>(b + i * 8), b1 = *reinterpret_cast<const f32x4*>(b + i * 8 + 4);
+    float fa[8] = {a0[0] - b0[0], a0[1] - b0[1], a0[2] - b0[2], a0[3] - b0[3],
+                   a1[0] - b1[0], a1[1] - b1[1], a1[2] - b1[2], a1[3] - b1[3]};
+    float fg[8];
     if (g && accumulate) unpack8s(*reinterpret_cast<const u32x4*>(g + i * 8), fg);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float d = fa[q] - fb[q];
+      float d = fa[q];
       acc += d * d;
       fa[q] = grad_scale * d + ((g && accumulate) ? fg[q] : 0.f);
     }
@@ -439,14 +441,14 @@ __global__ void mse_tap_kernel(const bf16_t* __restrict__ a, const bf16_t* __res
   if (threadIdx.x == 0 && loss) atomicAdd(loss, t * loss_scale);
 }
 
-// a, b, g: contiguous bf16 arrays of n elements (n % 8 == 0)
+// a, b: contiguous fp32 arrays of n elements (n % 8 == 0); g: bf16 [n] or null
 extern "C" int ried_mse_tap(const void* a, const void* b, long long n, float loss_scale, float* loss, void* g,
                             float grad_scale, int accumulate, hipStream_t stream) {
   RIED_CHECK_ARG(a && b && n > 0 && n % 8 == 0, "ried_mse_tap: bad arguments");
   RIED_CHECK_ARG(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)g % 16) == 0,
                  "ried_mse_tap: alignment");
   hipLaunchKernelGGL(mse_tap_kernel, dim3(ew_grid(n / 8, SP_THREADS * 2, 1024)), dim3(SP_THREADS), 0, stream,
-                     (const bf16_t*)a, (const bf16_t*)b, n / 8, loss_scale, loss, (bf16_t*)g, grad_scale, accumulate);
+                     (const float*)a, (const float*)b, n / 8, loss_scale, loss, (bf16_t*)g, grad_scale, accumulate);
   RIED_CHECK_LAUNCH("ried_mse_tap");
   return RIED_OK;
 }
@@ -509,5 +511,22 @@ extern "C" int ried_fill(void* out, long long ldo, long long npix, int C, const 
   hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(npix * (C / 8), SP_THREADS, 2048)), dim3(SP_THREADS), 0, stream,
                      (bf16_t*)out, ldo, npix, C, s, value);
   RIED_CHECK_LAUNCH("ried_fill");
+  return RIED_OK;
+}
+
+// out[0] += scale * sum_i in[i*stride]
+__global__ void sum_f32_kernel(const float* __restrict__ in, long long n, long long stride, float scale,
+                               float* __restrict__ out) {
+  __shared__ float sh[4];
+  float acc = 0.f;
+  for (long long i = threadIdx.x; i < n; i += blockDim.x) acc += in[i * stride];
+  float t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) atomicAdd(out, t * scale);
+}
+extern "C" int ried_sum_f32(const float* in, long long n, long long stride, float scale, float* out,
+                            hipStream_t stream) {
+  RIED_CHECK_ARG(in && out && n > 0 && stride > 0, "ried_sum_f32: bad arguments");
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(256), 0, stream, in, n, stride, scale, out);
+  RIED_CHECK_LAUNCH("ried_sum_f32");
   return RIED_OK;
 }

@@ -1,0 +1,915 @@
+"""Static execution plans for the RIED-GAN hot path on one MI355X.
+
+A plan is built once per (module, batch, H, W): every activation, gradient and
+scratch buffer is allocated up front in HBM (NHWC bf16, channel-sliced
+concatenation buffers, fp32 master weights in one flat buffer), and forward /
+backward are fixed sequences of launches into libried_gan.so on the current
+HIP stream with no host synchronisation, so a whole training step can be
+captured into one HIP graph.
+
+Layer classes follow the reference's modules (src/rinet.py) one to one:
+ConvBN = BasicConv2d / BasicDeconv2d, Inception{A..E}, SNConv, Attn,
+Generator = RIGAN, Discriminator = ImageDiscriminator; Vgg is the frozen
+VGG16 tap extractor of src/loss.py:69-87.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import ops
+from .ops import View
+
+F32 = torch.float32
+_NON_TRAINABLE = ("running_mean", "running_var", "num_batches_tracked", "weight_u", "weight_v")
+
+
+def is_trainable(name: str) -> bool:
+    return not name.endswith(_NON_TRAINABLE)
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+# --------------------------------------------------------------------------- parameter store
+class State:
+    """Parameters of one network: trainable tensors are views into one flat fp32 buffer (so Adam and the
+    gradient all-reduce are single launches over `flat` / `flat_grad`); buffers keep their own storage."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], device="cuda"):
+        self.device = device
+        names = [k for k in sd if is_trainable(k)]
+        offs, total = {}, 0
+        for k in names:
+            offs[k] = total
+            total += (sd[k].numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
+        self.flat = torch.zeros(total, dtype=F32, device=device)
+        self.flat_grad = torch.zeros(total, dtype=F32, device=device)
+        self.p: Dict[str, torch.Tensor] = {}
+        self.g: Dict[str, torch.Tensor] = {}
+        self.b: Dict[str, torch.Tensor] = {}
+        for k in names:
+            n = sd[k].numel()
+            self.p[k] = self.flat[offs[k]:offs[k] + n].view(sd[k].shape)
+            self.g[k] = self.flat_grad[offs[k]:offs[k] + n].view(sd[k].shape)
+            self.p[k].copy_(sd[k].detach().to(F32))
+        for k in sd:
+            if not is_trainable(k):
+                self.b[k] = sd[k].detach().clone().to(device)
+        self.adam_m = torch.zeros_like(self.flat)
+        self.adam_v = torch.zeros_like(self.flat)
+        self.adam_step = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = {k: v.detach().clone() for k, v in self.p.items()}
+        out.update({k: v.detach().clone() for k, v in self.b.items()})
+        return out
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]):
+        for k, v in sd.items():
+            (self.p if k in self.p else self.b)[k].copy_(v)
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def adam(self, lr: float, b1=0.01, b2=0.99, eps=1e-8):
+        ops.adam(self.flat, self.flat_grad, self.adam_m, self.adam_v, lr, self.adam_step, b1, b2, eps)
+
+
+# --------------------------------------------------------------------------- buffers
+class Act:
+    """An activation view and (when gradients are wanted) the gradient view of the same shape."""
+
+    def __init__(self, v: View, g: Optional[View]):
+        self.v, self.g = v, g
+
+    def slice(self, c0, c1) -> "Act":
+        return Act(self.v.slice(c0, c1), None if self.g is None else self.g.slice(c0, c1))
+
+    def images(self, n0, n1) -> "Act":
+        return Act(self.v.images(n0, n1), None if self.g is None else self.g.images(n0, n1))
+
+
+class Ctx:
+    """Allocation context of one plan.  Gradient views come from one arena that a single memset clears."""
+
+    def __init__(self, state: Optional[State], device="cuda", grads: bool = True, training: bool = True):
+        self.st, self.device, self.grads, self.training = state, device, grads, training
+        self._grad_views: List[Tuple[View, int]] = []
+        self._grad_bytes = 0
+        self.grad_arena: Optional[torch.Tensor] = None
+        self._f32: List[Tuple[torch.Tensor, int, int]] = []
+        self.stats_elems = 0          # fp32 arena zeroed at the start of every forward (BN sums)
+        self.sums_elems = 0           # fp32 arena zeroed at the start of every backward
+        self.slab_elems = 0
+        self.tmp_elems = 0
+        self._stats_req: List[Tuple[object, str, int]] = []
+        self._sums_req: List[Tuple[object, str, int]] = []
+
+    # activations
+    def act(self, N, H, W, C, grad: Optional[bool] = None) -> Act:
+        v = ops.new_view(N, H, W, C, self.device)
+        want = self.grads if grad is None else grad
+        g = None
+        if want:
+            g = View(None, self._grad_bytes, C, C, N, H, W)   # ptr = offset until finalize()
+            self._grad_views.append((g, self._grad_bytes))
+            self._grad_bytes += (N * H * W * C * 2 + 255) // 256 * 256
+        return Act(v, g)
+
+    def stats(self, owner, attr, n):
+        self._stats_req.append((owner, attr, self.stats_elems))
+        self.stats_elems += (n + 3) // 4 * 4
+        setattr(owner, attr + "_n", n)
+
+    def sums(self, owner, attr, n):
+        self._sums_req.append((owner, attr, self.sums_elems))
+        self.sums_elems += (n + 3) // 4 * 4
+        setattr(owner, attr + "_n", n)
+
+    def need_slab(self, n):
+        self.slab_elems = max(self.slab_elems, n)
+
+    def need_tmp(self, n):
+        self.tmp_elems = max(self.tmp_elems, n)
+
+    def finalize(self):
+        dev = self.device
+        self.grad_arena = torch.zeros(max(self._grad_bytes // 2, 8), dtype=torch.bfloat16, device=dev)
+        base = self.grad_arena.data_ptr()
+        seen = set()
+        for g, off in self._grad_views:
+            if id(g) not in seen:
+                g.base, g.ptr = self.grad_arena, base + off
+                seen.add(id(g))
+        self.stats_arena = torch.zeros(max(self.stats_elems, 4), dtype=F32, device=dev)
+        self.sums_arena = torch.zeros(max(self.sums_elems, 4), dtype=F32, device=dev)
+        for owner, attr, off in self._stats_req:
+            setattr(owner, attr, self.stats_arena[off:off + getattr(owner, attr + "_n")])
+        for owner, attr, off in self._sums_req:
+            setattr(owner, attr, self.sums_arena[off:off + getattr(owner, attr + "_n")])
+        self.slab = torch.empty(max(self.slab_elems, 4), dtype=F32, device=dev)
+        self.tmp = torch.empty(max(self.tmp_elems, 8), dtype=torch.bfloat16, device=dev)
+
+    def tmp_view(self, N, H, W, C) -> View:
+        assert N * H * W * C <= self.tmp.numel()
+        return View(self.tmp, self.tmp.data_ptr(), C, C, N, H, W)
+
+    def zero_stats(self):
+        self.stats_arena.zero_()
+
+    def zero_backward(self):
+        self.grad_arena.zero_()
+        self.sums_arena.zero_()
+
+
+# Deferred gradient pointers: Views handed out before Ctx.finalize() hold offsets.  Slices taken before
+# finalize() must be re-derived afterwards, so layers keep (parent Act, c0, c1) and slice on use.
+class Slot:
+    """A channel slice [c0, c1) of an Act, resolved at run time (after the gradient arena exists)."""
+
+    def __init__(self, act: Act, c0: int = 0, c1: Optional[int] = None, n0: int = 0, n1: Optional[int] = None):
+        self.act, self.c0, self.c1 = act, c0, act.v.C if c1 is None else c1
+        self.n0, self.n1 = n0, act.v.N if n1 is None else n1
+
+    @property
+    def C(self):
+        return self.c1 - self.c0
+
+    @property
+    def v(self) -> View:
+        v = self.act.v
+        if (self.n0, self.n1) != (0, v.N):
+            v = v.images(self.n0, self.n1)
+        return v if (self.c0, self.c1) == (0, v.C) else v.slice(self.c0, self.c1)
+
+    @property
+    def g(self) -> View:
+        g = self.act.g
+        if (self.n0, self.n1) != (0, g.N):
+            g = g.images(self.n0, self.n1)
+        return g if (self.c0, self.c1) == (0, g.C) else g.slice(self.c0, self.c1)
+
+    def sub(self, c0, c1) -> "Slot":
+        return Slot(self.act, self.c0 + c0, self.c0 + c1, self.n0, self.n1)
+
+    def images(self, n0, n1) -> "Slot":
+        return Slot(self.act, self.c0, self.c1, self.n0 + n0, self.n0 + n1)
+
+    @property
+    def shape(self):
+        v = self.act.v
+        return (self.n1 - self.n0, v.H, v.W, self.C)
+
+
+def _splitk(blocks: int, kpix: int, target: int = 768) -> int:
+    s = max(1, min((target + blocks - 1) // blocks, (kpix + 127) // 128))
+    return min(s, 512)
+
+
+def _conv_out(h, k, s, p):
+    return (h + 2 * p - k) // s + 1
+
+
+# --------------------------------------------------------------------------- conv (+BN+ReLU) layers
+class ConvCore:
+    """Weight handling shared by every bf16 conv / deconv layer: packing, forward, dgrad, wgrad."""
+
+    def __init__(self, ctx: Ctx, wname: str, cin, cout, k, stride, pad, deconv: bool, xin: Slot, need_dx: bool,
+                 need_wgrad: bool = True):
+        self.ctx, self.wname = ctx, wname
+        self.cin, self.cout = cin, cout
+        self.kh, self.kw = _pair(k)
+        self.sh, self.sw = _pair(stride)
+        self.ph, self.pw = _pair(pad)
+        self.deconv, self.xin, self.need_dx = deconv, xin, need_dx
+        N, H, W, C = xin.shape
+        assert C == cin, (wname, C, cin)
+        self.N, self.H, self.W = N, H, W
+        if deconv:
+            self.Ho = (H - 1) * self.sh - 2 * self.ph + self.kh
+            self.Wo = (W - 1) * self.sw - 2 * self.pw + self.kw
+        else:
+            self.Ho, self.Wo = _conv_out(H, self.kh, self.sh, self.ph), _conv_out(W, self.kw, self.sw, self.pw)
+        taps = self.kh * self.kw
+        dev = ctx.device
+        self.wp = torch.empty(cout * taps * cin, dtype=torch.bfloat16, device=dev)
+        self.wpt = torch.empty(cout * taps * cin, dtype=torch.bfloat16, device=dev) if (need_dx and ctx.grads) else None
+        if ctx.grads and need_wgrad:
+            # weight gradient: gathered tensor g / pixel-indexed tensor p (see ried_conv2d_wgrad)
+            cg, cp = (cout, cin) if deconv else (cin, cout)
+            kp = N * (H * W if deconv else self.Ho * self.Wo)
+            big = not (cg <= 64 and cp <= 64)
+            tiles = ((cg + 127) // 128) * ((cp + 127) // 128) if big else 1
+            self.splitk = _splitk(tiles * taps, kp)
+            ctx.need_slab(self.splitk * taps * cin * cout)
+
+    def weight(self) -> torch.Tensor:
+        return self.ctx.st.p[self.wname]
+
+    def pack_fwd(self, sigma=None):
+        ci, co, kh, kw = self.cin, self.cout, self.kh, self.kw
+        t = kh * kw
+        if self.deconv:   # master (Cin,Cout,kh,kw) -> [Cout][kh][kw][Cin]
+            ops.pack_weight(self.weight(), self.wp, co, kh, kw, ci, t, kw, 1, co * t, sigma)
+        else:             # master (Cout,Cin,kh,kw) -> [Cout][kh][kw][Cin]
+            ops.pack_weight(self.weight(), self.wp, co, kh, kw, ci, ci * t, kw, 1, t, sigma)
+
+    def pack_bwd(self, sigma=None):
+        ci, co, kh, kw = self.cin, self.cout, self.kh, self.kw
+        t = kh * kw
+        if self.deconv:   # -> [Cin][kh][kw][Cout]
+            ops.pack_weight(self.weight(), self.wpt, ci, kh, kw, co, co * t, kw, 1, t, sigma)
+        else:
+            ops.pack_weight(self.weight(), self.wpt, ci, kh, kw, co, t, kw, 1, ci * t, sigma)
+
+    def conv(self, y: View, **kw):
+        ops.conv2d(self.xin.v, self.wp, y, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
+                   transposed=self.deconv, **kw)
+
+    def dgrad(self, dy: View, dx: View):
+        """dx += data gradient of dy (d loss / d conv output)."""
+        ops.conv2d(dy, self.wpt, dx, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
+                   transposed=not self.deconv, accumulate=True)
+
+    def wgrad(self, dy: View, out: torch.Tensor, x: Optional[View] = None, accumulate=False):
+        """out (master layout) (+)= weight gradient."""
+        ctx, t = self.ctx, self.kh * self.kw
+        x = self.xin.v if x is None else x
+        if self.deconv:
+            ops.conv2d_wgrad(dy, x, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, ctx.slab, self.splitk)
+            ops.wgrad_reduce(ctx.slab, self.splitk, t, self.cin, self.cout, out, 1, self.cout * t, t,
+                             accumulate=accumulate)
+        else:
+            ops.conv2d_wgrad(x, dy, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, ctx.slab, self.splitk)
+            ops.wgrad_reduce(ctx.slab, self.splitk, t, self.cout, self.cin, out, 1, self.cin * t, t,
+                             accumulate=accumulate)
+
+
+class ConvBN:
+    """BasicConv2d / BasicDeconv2d (src/rinet.py:183-205): conv(no bias) -> BatchNorm2d -> ReLU.
+
+    The conv epilogue accumulates the per-channel sum / sum of squares; bn_apply writes relu(bn(x)) into `out`
+    (a channel slice of the consumer's input buffer), optionally adding onto what is there (residual sum)."""
+
+    def __init__(self, ctx: Ctx, prefix: str, cin, cout, k, stride, pad, xin: Slot, out: Slot, deconv=False,
+                 accumulate=False, need_dx=True, conv_key=None, bn_key=None):
+        self.ctx, self.prefix = ctx, prefix
+        conv_key = conv_key or (prefix + (".deconv" if deconv else ".conv"))
+        self.bn = bn_key or (prefix + ".bn")
+        self.core = ConvCore(ctx, conv_key + ".weight", cin, cout, k, stride, pad, deconv, xin, need_dx)
+        c = self.core
+        assert out.shape == (c.N, c.Ho, c.Wo, cout), (prefix, out.shape, (c.N, c.Ho, c.Wo, cout))
+        self.out, self.accumulate = out, accumulate
+        self.raw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
+        self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
+        ctx.stats(self, "stats", 2 * cout)
+        if ctx.grads:
+            ctx.sums(self, "sums", 2 * cout)
+            ctx.need_tmp(c.N * c.Ho * c.Wo * cout)
+
+    def forward(self):
+        ctx, c, st = self.ctx, self.core, self.ctx.st
+        c.pack_fwd()
+        if ctx.training:
+            c.conv(self.raw, stats=self.stats)
+            ops.bn_finalize(self.stats, c.cout, self.raw.npix, self.save, st.b[self.bn + ".running_mean"],
+                            st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"])
+        else:
+            c.conv(self.raw)
+            ops.bn_eval_stats(st.b[self.bn + ".running_mean"], st.b[self.bn + ".running_var"], c.cout, self.save)
+        ops.bn_apply(self.raw, self.out.v, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
+                     relu=True, accumulate=self.accumulate)
+
+    def backward(self):
+        """Reads out.g; writes weight / BN gradients; accumulates into xin.g when need_dx."""
+        ctx, c, st = self.ctx, self.core, self.ctx.st
+        draw = ctx.tmp_view(c.N, c.Ho, c.Wo, c.cout)
+        ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
+                        self.sums, st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True)
+        c.wgrad(draw, st.g[c.wname])
+        if c.need_dx:
+            c.pack_bwd()
+            c.dgrad(draw, c.xin.g)
+
+
+class ConvBNC1:
+    """Generator conv1: 3x3 s2 p1 on the one-channel fp32 image, then BN + ReLU (src/rinet.py:55)."""
+
+    def __init__(self, ctx: Ctx, prefix: str, cout, N, H, W, out: Slot):
+        self.ctx, self.prefix, self.cout = ctx, prefix, cout
+        self.N, self.H, self.W = N, H, W
+        self.Ho, self.Wo = _conv_out(H, 3, 2, 1), _conv_out(W, 3, 2, 1)
+        assert out.shape == (N, self.Ho, self.Wo, cout)
+        self.out = out
+        self.raw = ops.new_view(N, self.Ho, self.Wo, cout, ctx.device)
+        self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
+        ctx.stats(self, "stats", 2 * cout)
+        if ctx.grads:
+            ctx.sums(self, "sums", 2 * cout)
+            ctx.need_tmp(N * self.Ho * self.Wo * cout)
+        self.x: Optional[torch.Tensor] = None
+
+    def forward(self, x: torch.Tensor):
+        ctx, st, bn = self.ctx, self.ctx.st, self.prefix + ".bn"
+        self.x = x
+        w = st.p[self.prefix + ".conv.weight"]
+        if ctx.training:
+            ops.conv_c1_fwd(x, w, self.raw, 2, stats=self.stats)
+            ops.bn_finalize(self.stats, self.cout, self.raw.npix, self.save, st.b[bn + ".running_mean"],
+                            st.b[bn + ".running_var"], st.b[bn + ".num_batches_tracked"])
+        else:
+            ops.conv_c1_fwd(x, w, self.raw, 2)
+            ops.bn_eval_stats(st.b[bn + ".running_mean"], st.b[bn + ".running_var"], self.cout, self.save)
+        ops.bn_apply(self.raw, self.out.v, self.save, st.p[bn + ".weight"], st.p[bn + ".bias"], relu=True)
+
+    def backward(self):
+        ctx, st, bn = self.ctx, self.ctx.st, self.prefix + ".bn"
+        draw = ctx.tmp_view(self.N, self.Ho, self.Wo, self.cout)
+        ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[bn + ".weight"], st.p[bn + ".bias"], self.sums,
+                        st.g[bn + ".weight"], st.g[bn + ".bias"], relu=True)
+        ops.conv_c1_wgrad(self.x, draw, 2, st.g[self.prefix + ".conv.weight"])   # grads were zeroed: += is =
+
+
+class ConvPlain:
+    """A bare 1x1 Conv2d without bias, BN or activation (the `sample.0` of decoder blocks, src/rinet.py:265,360)."""
+
+    def __init__(self, ctx: Ctx, wname: str, cin, cout, xin: Slot, out: Slot):
+        self.ctx, self.out = ctx, out
+        self.core = ConvCore(ctx, wname, cin, cout, 1, 1, 0, False, xin, True)
+
+    def forward(self):
+        self.core.pack_fwd()
+        self.core.conv(self.out.v)
+
+    def backward(self):
+        c, st = self.core, self.ctx.st
+        c.wgrad(self.out.g, st.g[c.wname])
+        c.pack_bwd()
+        c.dgrad(self.out.g, c.xin.g)
+
+
+class Pool:
+    def __init__(self, ctx: Ctx, mode: int, xin: Slot, out: Slot):
+        self.mode, self.xin, self.out = mode, xin, out
+
+    def forward(self):
+        ops.pool_fwd(self.xin.v, self.out.v, self.mode)
+
+    def backward(self):
+        ops.pool_bwd(None if self.mode == ops.POOL_AVG3 else self.xin.v, self.out.g, self.xin.g, self.mode)
+
+
+class Upsample:
+    def __init__(self, ctx: Ctx, xin: Slot, out: Slot):
+        self.xin, self.out = xin, out
+
+    def forward(self):
+        ops.upsample2x_fwd(self.xin.v, self.out.v)
+
+    def backward(self):
+        ops.upsample2x_bwd(self.out.g, self.xin.g)
+
+
+class Seq:
+    """Layers run in order forward and in reverse order backward."""
+
+    def __init__(self, layers=None):
+        self.layers = list(layers or [])
+
+    def add(self, layer):
+        self.layers.append(layer)
+        return layer
+
+    def forward(self):
+        for l in self.layers:
+            l.forward()
+
+    def backward(self):
+        for l in reversed(self.layers):
+            l.backward()
+
+
+class Identity:
+    """Residual identity without a downsample conv: out = x (then branches add onto it)."""
+
+    def __init__(self, xin: Slot, out: Slot):
+        self.xin, self.out = xin, out
+
+    def forward(self):
+        ops.ew(ops.EW_COPY, self.xin.v, self.out.v)
+
+    def backward(self):
+        ops.ew(ops.EW_ADD, self.out.g, self.xin.g)
+
+
+def _chain(ctx: Ctx, seq: Seq, prefix: str, specs, xin: Slot, out: Slot, deconv=False, accumulate=False):
+    """specs: [(name, cin, cout, k, stride, pad)]; the last layer writes `out`, inner layers get own buffers."""
+    cur = xin
+    for i, (name, cin, cout, k, s, p) in enumerate(specs):
+        last = i == len(specs) - 1
+        N, H, W, _ = cur.shape
+        kh, kw = _pair(k); sh, sw = _pair(s); ph, pw = _pair(p)
+        if deconv:
+            Ho, Wo = (H - 1) * sh - 2 * ph + kh, (W - 1) * sw - 2 * pw + kw
+        else:
+            Ho, Wo = _conv_out(H, kh, sh, ph), _conv_out(W, kw, sw, pw)
+        dst = out if last else Slot(ctx.act(N, Ho, Wo, cout))
+        seq.add(ConvBN(ctx, prefix + "." + name, cin, cout, k, s, p, cur, dst, deconv=deconv,
+                       accumulate=accumulate and last))
+        cur = dst
+    return cur
+
+
+def _residual_head(ctx, seq, prefix, xin: Slot, out: Slot, cin, cout, has_ds):
+    if has_ds:   # identity_downsample = Conv1x1 + BN + ReLU (src/rinet.py:99-103)
+        seq.add(ConvBN(ctx, prefix + ".identity_downsample", cin, cout, 1, 1, 0, xin, out,
+                       conv_key=prefix + ".identity_downsample.0", bn_key=prefix + ".identity_downsample.1"))
+    else:
+        assert cin == cout
+        seq.add(Identity(xin, out))
+
+
+def inception_a(ctx, prefix, xin: Slot, out: Slot, cin, has_ds) -> Seq:
+    """src/rinet.py:207-252: out = cat(32|32|48|16) + identity."""
+    s = Seq()
+    _residual_head(ctx, s, prefix, xin, out, cin, 128, has_ds)
+    _chain(ctx, s, prefix, [("branch1x1", cin, 32, 1, 1, 0)], xin, out.sub(0, 32), accumulate=True)
+    _chain(ctx, s, prefix, [("branch3x3_1", cin, 16, 1, 1, 0), ("branch3x3_2", 16, 32, 3, 1, 1)], xin,
+           out.sub(32, 64), accumulate=True)
+    _chain(ctx, s, prefix, [("branch3x3dbl_1", cin, 32, 1, 1, 0), ("branch3x3dbl_2", 32, 48, 3, 1, 1),
+                            ("branch3x3dbl_3", 48, 48, 3, 1, 1)], xin, out.sub(64, 112), accumulate=True)
+    N, H, W, _ = xin.shape
+    pooled = Slot(ctx.act(N, H, W, cin))
+    s.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
+    _chain(ctx, s, prefix, [("branch_pool", cin, 16, 1, 1, 0)], pooled, out.sub(112, 128), accumulate=True)
+    return s
+
+
+def inception_c(ctx, prefix, xin: Slot, out: Slot, cin, c7, has_ds) -> Seq:
+    """src/rinet.py:293-347: out = cat(64|64|64|64) + identity."""
+    s = Seq()
+    _residual_head(ctx, s, prefix, xin, out, cin, 256, has_ds)
+    h, v = ((1, 7), 1, (0, 3)), ((7, 1), 1, (3, 0))
+    _chain(ctx, s, prefix, [("branch1x1", cin, 64, 1, 1, 0)], xin, out.sub(0, 64), accumulate=True)
+    _chain(ctx, s, prefix, [("branch7x7_1", cin, c7, 1, 1, 0), ("branch7x7_2", c7, c7, *h),
+                            ("branch7x7_3", c7, 64, *v)], xin, out.sub(64, 128), accumulate=True)
+    _chain(ctx, s, prefix, [("branch7x7dbl_1", cin, c7, 1, 1, 0), ("branch7x7dbl_2", c7, c7, *v),
+                            ("branch7x7dbl_3", c7, c7, *h), ("branch7x7dbl_4", c7, c7, *v),
+                            ("branch7x7dbl_5", c7, 64, *h)], xin, out.sub(128, 192), accumulate=True)
+    N, H, W, _ = xin.shape
+    pooled = Slot(ctx.act(N, H, W, cin))
+    s.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
+    _chain(ctx, s, prefix, [("branch_pool", cin, 64, 1, 1, 0)], pooled, out.sub(192, 256), accumulate=True)
+    return s
+
+
+def inception_e(ctx, prefix, xin: Slot, out: Slot, cin, has_ds) -> Seq:
+    """src/rinet.py:389-445: out = cat(160 | 192,192 | 192,192 | 96) + identity."""
+    s = Seq()
+    _residual_head(ctx, s, prefix, xin, out, cin, 1024, has_ds)
+    N, H, W, _ = xin.shape
+    _chain(ctx, s, prefix, [("branch1x1", cin, 160, 1, 1, 0)], xin, out.sub(0, 160), accumulate=True)
+    b3 = _chain(ctx, s, prefix, [("branch3x3_1", cin, 192, 1, 1, 0)], xin, Slot(ctx.act(N, H, W, 192)))
+    _chain(ctx, s, prefix, [("branch3x3_2a", 192, 192, (1, 3), 1, (0, 1))], b3, out.sub(160, 352), accumulate=True)
+    _chain(ctx, s, prefix, [("branch3x3_2b", 192, 192, (3, 1), 1, (1, 0))], b3, out.sub(352, 544), accumulate=True)
+    bd = _chain(ctx, s, prefix, [("branch3x3dbl_1", cin, 224, 1, 1, 0), ("branch3x3dbl_2", 224, 192, 3, 1, 1)], xin,
+                Slot(ctx.act(N, H, W, 192)))
+    _chain(ctx, s, prefix, [("branch3x3dbl_3a", 192, 192, (1, 3), 1, (0, 1))], bd, out.sub(544, 736), accumulate=True)
+    _chain(ctx, s, prefix, [("branch3x3dbl_3b", 192, 192, (3, 1), 1, (1, 0))], bd, out.sub(736, 928), accumulate=True)
+    pooled = Slot(ctx.act(N, H, W, cin))
+    s.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
+    _chain(ctx, s, prefix, [("branch_pool", cin, 96, 1, 1, 0)], pooled, out.sub(928, 1024), accumulate=True)
+    return s
+
+
+def _grid_tail(ctx, s, prefix, xin: Slot, out_slice: Slot, cin, cs, decoder):
+    N, H, W, _ = xin.shape
+    if decoder:   # sample = conv1x1(no bias) + bilinear x2, align_corners (src/rinet.py:264-267, 359-362)
+        mid = Slot(ctx.act(N, H, W, cs))
+        s.add(ConvPlain(ctx, prefix + ".sample.0.weight", cin, cs, xin, mid))
+        s.add(Upsample(ctx, mid, out_slice))
+    else:
+        s.add(Pool(ctx, ops.POOL_MAX3S2, xin, out_slice))
+
+
+def inception_b(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
+    """src/rinet.py:254-291: cat(64 | 64 | maxpool(cin) or sample(128))."""
+    s = Seq()
+    k = 4 if decoder else 3
+    _chain(ctx, s, prefix, [("branch3x3_1", cin, 32, 1, 1, 0), ("branch3x3_2", 32, 64, k, 2, 1)], xin,
+           out.sub(0, 64), deconv=decoder)
+    _chain(ctx, s, prefix, [("branch3x3dbl_1", cin, 32, 1, 1, 0), ("branch3x3dbl_2", 32, 48, 3, 1, 1),
+                            ("branch3x3dbl_3", 48, 64, k, 2, 1)], xin, out.sub(64, 128), deconv=decoder)
+    cs = 128 if decoder else cin
+    _grid_tail(ctx, s, prefix, xin, out.sub(128, 128 + cs), cin, cs, decoder)
+    return s
+
+
+def inception_d(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
+    """src/rinet.py:349-387: cat(128 | 128 | maxpool(cin) or sample(256))."""
+    s = Seq()
+    k = 4 if decoder else 3
+    _chain(ctx, s, prefix, [("branch3x3_1", cin, 64, 1, 1, 0), ("branch3x3_2", 64, 128, k, 2, 1)], xin,
+           out.sub(0, 128), deconv=decoder)
+    _chain(ctx, s, prefix, [("branch7x7x3_1", cin, 128, 1, 1, 0), ("branch7x7x3_2", 128, 128, (1, 7), 1, (0, 3)),
+                            ("branch7x7x3_3", 128, 128, (7, 1), 1, (3, 0)), ("branch7x7x3_4", 128, 128, k, 2, 1)],
+           xin, out.sub(128, 256), deconv=decoder)
+    cs = 256 if decoder else cin
+    _grid_tail(ctx, s, prefix, xin, out.sub(256, 256 + cs), cin, cs, decoder)
+    return s
+
+
+# --------------------------------------------------------------------------- generator
+class Generator:
+    """RIGAN (src/rinet.py:34-92) for a fixed (N, H, W).  x and the output are fp32 (N,1,H,W)."""
+
+    def __init__(self, state: State, N: int, H: int, W: int, grads=True, training=True, device="cuda"):
+        assert H % 16 == 0 and W % 16 == 0, "RIGAN needs H, W divisible by 16 (skip connections must line up)"
+        self.st = state
+        self.ctx = ctx = Ctx(state, device, grads, training)
+        self.N, self.H, self.W = N, H, W
+        h2, w2, h4, w4, h8, w8, h16, w16 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8, H // 16, W // 16
+        self.cat2 = Slot(ctx.act(N, h2, w2, 96))        # cat(conv1 (32), deconv1 (64))   src/rinet.py:89
+        self.cat1 = Slot(ctx.act(N, h4, w4, 192))       # cat(conv2 (64), layer_block_5 (128))   src/rinet.py:88
+        self.conv1 = ConvBNC1(ctx, "conv1", 32, N, H, W, self.cat2.sub(0, 32))
+        body = Seq()
+        c2 = self.cat1.sub(0, 64)
+        body.add(ConvBN(ctx, "conv2", 32, 64, 3, 2, 1, self.cat2.sub(0, 32), c2))
+        a1 = Slot(ctx.act(N, h4, w4, 128)); body.add(inception_a(ctx, "layer_block_1.0", c2, a1, 64, True))
+        a2 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_b(ctx, "reduce_grid_1", a1, a2, 128, False))
+        a3 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_c(ctx, "layer_block_2.0", a2, a3, 256, 64, False))
+        a4 = Slot(ctx.act(N, h16, w16, 512)); body.add(inception_d(ctx, "reduce_grid_2", a3, a4, 256, False))
+        a5 = Slot(ctx.act(N, h16, w16, 1024)); body.add(inception_e(ctx, "layer_block_3.0", a4, a5, 512, True))
+        a6 = Slot(ctx.act(N, h8, w8, 512)); body.add(inception_d(ctx, "expand_grid_1", a5, a6, 1024, True))
+        a7 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_c(ctx, "layer_block_4.0", a6, a7, 512, 64, True))
+        a8 = Slot(ctx.act(N, h4, w4, 256)); body.add(inception_b(ctx, "expand_grid_2", a7, a8, 256, True))
+        body.add(inception_a(ctx, "layer_block_5.0", a8, self.cat1.sub(64, 192), 256, True))
+        body.add(ConvBN(ctx, "deconv1", 192, 64, 4, 2, 1, self.cat1, self.cat2.sub(32, 96), deconv=True))
+        self.hlast = Slot(ctx.act(N, H, W, 32))
+        body.add(ConvBN(ctx, "deconv2", 96, 32, 4, 2, 1, self.cat2, self.hlast, deconv=True))
+        self.body = body
+        self.tops = {"conv1": self.cat2.sub(0, 32), "conv2": c2, "layer_block_1": a1, "reduce_grid_1": a2,
+                     "layer_block_2": a3, "reduce_grid_2": a4, "layer_block_3": a5, "expand_grid_1": a6,
+                     "layer_block_4": a7, "expand_grid_2": a8, "layer_block_5": self.cat1.sub(64, 192),
+                     "deconv1": self.cat2.sub(32, 96), "deconv2": self.hlast}
+        self.out = torch.empty(N, 1, H, W, dtype=F32, device=device)
+        ctx.finalize()
+        self.x = None
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        assert x.shape == (self.N, 1, self.H, self.W) and x.dtype == F32 and x.is_contiguous()
+        self.x = x
+        if self.ctx.training:
+            self.ctx.zero_stats()
+        self.conv1.forward(x)
+        self.body.forward()
+        ops.out_conv_fwd(x, self.hlast.v, self.st.p["out_conv.weight"], self.out)
+        return self.out
+
+    def backward(self, dout: torch.Tensor):
+        """dout: fp32 (N,1,H,W) = d loss / d output.  Fills state.g (which must be zero on entry)."""
+        assert dout.shape == self.out.shape and dout.dtype == F32 and dout.is_contiguous()
+        self.ctx.zero_backward()
+        ops.out_conv_bwd(self.x, self.hlast.v, self.st.p["out_conv.weight"], dout, self.hlast.g,
+                         self.st.g["out_conv.weight"])
+        self.body.backward()
+        self.conv1.backward()
+
+
+# --------------------------------------------------------------------------- discriminator
+class SNConv:
+    """SNConv2d (src/rinet.py:131-148): spectral-norm 3x3 conv pad 1 with bias, LeakyReLU(0.2)."""
+
+    def __init__(self, ctx: Ctx, prefix: str, cin, cout, stride, xin: Optional[Slot], out: Slot, first=False):
+        self.ctx, self.prefix, self.cin, self.cout, self.stride, self.first = ctx, prefix, cin, cout, stride, first
+        self.out = out
+        dev = ctx.device
+        self.K = cin * 9
+        self.sigma = torch.ones(1, dtype=F32, device=dev)
+        self.scratch = torch.zeros(self.K + cout + 2, dtype=F32, device=dev)
+        if not first:
+            self.core = ConvCore(ctx, prefix + ".weight_orig", cin, cout, 3, stride, 1, False, xin, True)
+        N, Ho, Wo, _ = out.shape
+        if ctx.grads:
+            ctx.need_tmp(N * Ho * Wo * cout)
+            self.dwsn = torch.empty(cout * self.K, dtype=F32, device=dev)
+        self.x_img: Optional[torch.Tensor] = None
+
+    def forward(self, x_img: Optional[torch.Tensor] = None):
+        st, p = self.ctx.st, self.prefix
+        w = st.p[p + ".weight_orig"]
+        ops.sn_sigma(w, self.cout, self.K, st.b[p + ".weight_u"], st.b[p + ".weight_v"], self.sigma, self.scratch,
+                     power_iter=self.ctx.training)
+        if self.first:
+            self.x_img = x_img
+            ops.conv_c1_fwd(x_img, w, self.out.v, self.stride, sigma=self.sigma, bias=st.p[p + ".bias"], act=2)
+        else:
+            self.core.pack_fwd(self.sigma)
+            self.core.conv(self.out.v, bias=st.p[p + ".bias"], act=2)
+
+    def backward(self, n0: int, n1: int, wgrad: bool, dimg: Optional[torch.Tensor] = None):
+        """Images [n0, n1) only.  wgrad: parameter gradients; dimg (first layer): fp32 image gradient, +=."""
+        ctx, st, p = self.ctx, self.ctx.st, self.prefix
+        out = self.out.images(n0, n1)
+        N, Ho, Wo, C = out.shape
+        dpre = ctx.tmp_view(N, Ho, Wo, C)
+        ops.ew(ops.EW_ACTBWD, out.g, dpre, y=out.v, slope=0.2)
+        if wgrad:
+            ops.colsum(dpre, st.g[p + ".bias"])
+            if self.first:
+                self.dwsn.zero_()
+                ops.conv_c1_wgrad(self.x_img[n0:n1], dpre, self.stride, self.dwsn)
+            else:
+                self.core.wgrad(dpre, self.dwsn, x=self.core.xin.images(n0, n1).v)
+            ops.sn_backward(self.dwsn, st.p[p + ".weight_orig"], st.b[p + ".weight_u"], st.b[p + ".weight_v"],
+                            self.sigma, self.cout, self.K, st.g[p + ".weight_orig"], self.scratch)
+        if self.first:
+            if dimg is not None:
+                ops.conv_c1_dgrad(dpre, st.p[p + ".weight_orig"], dimg, sigma=self.sigma, accumulate=True)
+        else:
+            self.core.pack_bwd(self.sigma)
+            self.core.dgrad(dpre, self.core.xin.images(n0, n1).g)
+
+
+class Attn:
+    """Self_Attn (src/rinet.py:150-181) on NHWC tokens: the q|k|v projections are one 1x1 conv with
+    concatenated output channels; energy, softmax and the value product are batched MFMA GEMMs."""
+
+    def __init__(self, ctx: Ctx, prefix: str, C: int, xin: Slot, out: Slot):
+        self.ctx, self.prefix, self.C, self.d = ctx, prefix, C, C // 8
+        self.xin, self.out = xin, out
+        N, H, W, _ = xin.shape
+        self.N, self.n = N, H * W
+        dev = ctx.device
+        self.cq = 2 * self.d + C
+        self.qkv = Slot(ctx.act(N, H, W, self.cq))
+        self.wp = torch.empty(self.cq * C, dtype=torch.bfloat16, device=dev)
+        self.wcat = torch.empty(self.cq, C, dtype=F32, device=dev)          # [q; k; v] projection weights
+        self.bias = torch.empty(self.cq, dtype=F32, device=dev)
+        self.S = torch.empty(N * self.n * self.n, dtype=F32, device=dev)
+        self.P = torch.empty(N * self.n * self.n, dtype=torch.bfloat16, device=dev)
+        self.O = ops.new_view(N, H, W, C, dev)
+        if ctx.grads:
+            self.wpt = torch.empty(self.cq * C, dtype=torch.bfloat16, device=dev)
+            self.dS = torch.empty(N * self.n * self.n, dtype=torch.bfloat16, device=dev)
+            self.dO = ops.new_view(N, H, W, C, dev)
+            self.dw = torch.empty(self.cq * C, dtype=F32, device=dev)
+            self.db = torch.zeros(self.cq, dtype=F32, device=dev)
+            kp = N * self.n
+            self.splitk = _splitk(((C + 127) // 128) * ((self.cq + 127) // 128), kp)
+            ctx.need_slab(self.splitk * self.cq * C)
+
+    def _names(self):
+        p = self.prefix
+        return [(p + ".query_conv", 0, self.d), (p + ".key_conv", self.d, 2 * self.d),
+                (p + ".value_conv", 2 * self.d, self.cq)]
+
+    def forward(self):
+        st, C, d, n, N = self.ctx.st, self.C, self.d, self.n, self.N
+        for name, c0, c1 in self._names():
+            self.wcat[c0:c1].copy_(st.p[name + ".weight"].view(c1 - c0, C))
+            self.bias[c0:c1].copy_(st.p[name + ".bias"])
+        ops.pack_weight(self.wcat, self.wp, self.cq, 1, 1, C, C, 1, 1, 1)
+        x, qkv = self.xin.v, self.qkv.v
+        ops.conv2d(x, self.wp, qkv, 1, 1, 1, 1, 0, 0, bias=self.bias)
+        q, k, v = qkv.ptr, qkv.ptr + 2 * d, qkv.ptr + 4 * d
+        ld, bs = qkv.ld, n * qkv.ld
+        # S[b][i][j] = q_i . k_j : m = j (A = k), n = i (B = q)
+        ops.bgemm(k, ld, bs, 0, q, ld, bs, 0, n, n, d, N, self.S.data_ptr(), n, n * n, out_f32=True)
+        ops.softmax_fwd(self.S, self.P, N * n, n)
+        # O[b][i][c] = sum_j P[i][j] v[j][c] : m = c (A = v stored [j][c]), n = i (B = P)
+        ops.bgemm(v, ld, bs, 1, self.P.data_ptr(), n, n * n, 0, C, n, n, N, self.O.ptr, C, n * C)
+        ops.ew(ops.EW_AXPY, self.O, self.out.v, y=x, s=st.p[self.prefix + ".gamma"])
+
+    def backward(self, n0: int, n1: int, wgrad: bool):
+        st, C, d, n = self.ctx.st, self.C, self.d, self.n
+        N = n1 - n0
+        out, xin, qkv = self.out.images(n0, n1), self.xin.images(n0, n1), self.qkv.images(n0, n1)
+        O, dO = self.O.images(n0, n1), self.dO.images(n0, n1)
+        gamma = st.p[self.prefix + ".gamma"]
+        ops.ew(ops.EW_ADD, out.g, xin.g)                                    # residual path
+        if wgrad:
+            ops.dot(out.g, O, 1.0, st.g[self.prefix + ".gamma"])
+        ops.ew(ops.EW_SCALE, out.g, dO, s=gamma)
+        ld, bs = qkv.v.ld, n * qkv.v.ld
+        q, k, v = qkv.v.ptr, qkv.v.ptr + 2 * d, qkv.v.ptr + 4 * d
+        dq, dk, dv = qkv.g.ptr, qkv.g.ptr + 2 * d, qkv.g.ptr + 4 * d
+        off = n0 * n * n
+        P = self.P.data_ptr() + 2 * off
+        dP = self.S.data_ptr() + 4 * off                                    # S is dead after the softmax: reuse
+        dS = self.dS.data_ptr() + 2 * off
+        # dP[i][j] = sum_c dO[i][c] v[j][c] : m = j (A = v [j][c]), n = i (B = dO)
+        ops.bgemm(v, ld, bs, 0, dO.ptr, C, n * C, 0, n, n, C, N, dP, n, n * n, out_f32=True)
+        # dv[j][c] = sum_i P[i][j] dO[i][c] : m = c (A = dO stored [i][c]), n = j (B = P stored [i][j])
+        ops.bgemm(dO.ptr, C, n * C, 1, P, n, n * n, 1, C, n, n, N, dv, ld, bs)
+        ops.softmax_bwd(self.S[off:], self.P[off:], self.dS[off:], N * n, n)
+        # dq[i][e] = sum_j dS[i][j] k[j][e] : m = e (A = k stored [j][e]), n = i (B = dS)
+        ops.bgemm(k, ld, bs, 1, dS, n, n * n, 0, d, n, n, N, dq, ld, bs)
+        # dk[j][e] = sum_i dS[i][j] q[i][e] : m = e (A = q stored [i][e]), n = j (B = dS stored [i][j])
+        ops.bgemm(q, ld, bs, 1, dS, n, n * n, 1, d, n, n, N, dk, ld, bs)
+        if wgrad:
+            self.db.zero_()
+            ops.colsum(qkv.g, self.db)
+            ops.conv2d_wgrad(xin.v, qkv.g, 1, 1, 1, 1, 0, 0, self.ctx.slab, self.splitk)
+            ops.wgrad_reduce(self.ctx.slab, self.splitk, 1, self.cq, C, self.dw, 1, C, 1)
+            for name, c0, c1 in self._names():
+                st.g[name + ".weight"].view(-1).add_(self.dw[c0 * C:c1 * C])
+                st.g[name + ".bias"].add_(self.db[c0:c1])
+        ops.pack_weight(self.wcat, self.wpt, C, 1, 1, self.cq, 1, 1, 1, C)   # [C][1][1][cq] for the data gradient
+        ops.conv2d(qkv.g, self.wpt, xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True)
+
+
+class Discriminator:
+    """ImageDiscriminator (src/rinet.py:10-32) for a fixed batch of N one-channel fp32 images."""
+
+    def __init__(self, state: State, N: int, H: int, W: int, grads=True, training=True, device="cuda"):
+        assert H % 16 == 0 and W % 16 == 0
+        self.st = state
+        self.ctx = ctx = Ctx(state, device, grads, training)
+        self.N, self.H, self.W = N, H, W
+        p = "discriminator_net."
+        a0 = Slot(ctx.act(N, H, W, 64))
+        a1 = Slot(ctx.act(N, H // 2, W // 2, 128))
+        a2 = Slot(ctx.act(N, H // 4, W // 4, 256))
+        a3 = Slot(ctx.act(N, H // 4, W // 4, 256))
+        a4 = Slot(ctx.act(N, H // 8, W // 8, 512))
+        a5 = Slot(ctx.act(N, H // 8, W // 8, 512))
+        a6 = Slot(ctx.act(N, H // 16, W // 16, 512))
+        self.acts = [a0, a1, a2, a3, a4, a5, a6]
+        self.layers = [
+            SNConv(ctx, p + "0.conv2d", 1, 64, 1, None, a0, first=True),
+            SNConv(ctx, p + "1.conv2d", 64, 128, 2, a0, a1),
+            SNConv(ctx, p + "2.conv2d", 128, 256, 2, a1, a2),
+            Attn(ctx, p + "3", 256, a2, a3),
+            SNConv(ctx, p + "4.conv2d", 256, 512, 2, a3, a4),
+            Attn(ctx, p + "5", 512, a4, a5),
+            SNConv(ctx, p + "6.conv2d", 512, 512, 2, a5, a6),
+        ]
+        ctx.finalize()
+        self.out_features = 512 * (H // 16) * (W // 16)
+
+    @property
+    def out(self) -> Slot:
+        return self.acts[-1]
+
+    def forward(self, x_img: torch.Tensor) -> Slot:
+        """x_img: fp32 (N,1,H,W).  Returns the last activation (N, H/16, W/16, 512) NHWC bf16."""
+        assert x_img.shape == (self.N, 1, self.H, self.W) and x_img.dtype == F32 and x_img.is_contiguous()
+        for i, l in enumerate(self.layers):
+            if i == 0:
+                l.forward(x_img)
+            else:
+                l.forward()
+        return self.acts[-1]
+
+    def backward(self, n0: int, n1: int, wgrad: bool, dimg: Optional[torch.Tensor] = None):
+        """The gradient wrt the last activation must already be in out.g for images [n0, n1); every other
+        gradient buffer must be zero (call ctx.zero_backward() before writing out.g)."""
+        for l in reversed(self.layers):
+            if isinstance(l, SNConv):
+                l.backward(n0, n1, wgrad, dimg)
+            else:
+                l.backward(n0, n1, wgrad)
+
+    def output_nchw(self) -> torch.Tensor:
+        """(N, 8192-like) fp32 in the reference's flattening order (C, H, W) (src/rinet.py:31)."""
+        v = self.acts[-1].v
+        y = torch.empty(v.N, v.C, v.H, v.W, dtype=F32, device=self.ctx.device)
+        ops.nhwc_to_nchw(v, y)
+        return y.view(v.N, -1)
+
+
+# --------------------------------------------------------------------------- VGG16 taps
+VGG_CFG = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512]
+VGG_TAPS = (3, 8, 15, 22, 29)
+
+
+class Vgg:
+    """Frozen VGG16 features[0:30] with the five post-ReLU taps of src/loss.py:71-87, run on the batch
+    [prediction; target] (2B one-channel fp32 images, normalised on load as normalize_ does).  The three
+    identical input channels of torch.cat([x,x,x]) (src/loss.py:181-182) are folded into the first layer's
+    weights.  backward() propagates only through the prediction half and only to the data."""
+
+    def __init__(self, weights: Dict[str, torch.Tensor], B: int, H: int, W: int, grads=True, device="cuda"):
+        self.ctx = ctx = Ctx(None, device, grads, training=False)
+        self.B, self.H, self.W = B, H, W
+        N = 2 * B
+        dev = device
+        self.w0 = weights["0.weight"].to(dev, F32).sum(1).reshape(64, 9).contiguous()     # fold 3 -> 1 channel
+        self.b0 = weights["0.bias"].to(dev, F32).contiguous()
+        self.layers = []      # ("conv", idx, ConvCore, bias, out Slot) | ("pool", Pool)
+        self.taps: List[Slot] = []
+        cur = Slot(ctx.act(N, H, W, 64))
+        self.a0 = cur
+        idx, cin, h, w = 2, 64, H, W
+        for v in VGG_CFG[1:]:
+            if v == "M":
+                nxt = Slot(ctx.act(N, h // 2, w // 2, cin))
+                self.layers.append(("pool", Pool(ctx, ops.POOL_MAX2S2, cur, nxt)))
+                h, w = h // 2, w // 2
+                idx += 1
+            else:
+                nxt = Slot(ctx.act(N, h, w, v))
+                core = ConvCore(ctx, f"{idx}.weight", cin, v, 3, 1, 1, False, cur, True, need_wgrad=False)
+                wt = weights[f"{idx}.weight"].to(dev, F32).contiguous()
+                ops.pack_weight(wt, core.wp, v, 3, 3, cin, cin * 9, 3, 1, 9)
+                if grads:
+                    ops.pack_weight(wt, core.wpt, cin, 3, 3, v, 9, 3, 1, cin * 9)
+                cin = v
+                idx += 2
+                tap32 = None
+                if idx - 1 in VGG_TAPS:        # taps are also kept in fp32: the loss is a small difference
+                    tap32 = torch.empty(N, h, w, v, dtype=F32, device=dev)
+                    self.taps.append((nxt, tap32))
+                self.layers.append(("conv", core, weights[f"{idx - 2}.bias"].to(dev, F32).contiguous(), nxt, tap32))
+                if grads:
+                    ctx.need_tmp(B * h * w * v)
+            cur = nxt
+        if grads:
+            ctx.need_tmp(B * H * W * 64)
+        ctx.finalize()
+        torch.cuda.synchronize()
+
+    def forward(self, imgs: torch.Tensor):
+        """imgs: fp32 (2B,1,H,W): prediction images first, then targets."""
+        ops.conv_c1_fwd(imgs, self.w0, self.a0.v, 1, bias=self.b0, in_scale=1.0 / 4096.0, in_shift=0.25, act=1)
+        for l in self.layers:
+            if l[0] == "pool":
+                l[1].forward()
+            else:
+                _, core, bias, out, tap32 = l
+                core.conv(out.v, bias=bias, act=1, y2=tap32)
+
+    def loss_and_seed(self, loss: torch.Tensor, weight: float):
+        """loss[0] += mean over taps of MSE(tap(pred), tap(target)); seeds each tap's gradient (prediction
+        half) with weight * d/d tap.  Gradient buffers must be zero."""
+        B = self.B
+        for t, t32 in self.taps:
+            v = t.v
+            n = B * v.H * v.W * v.C
+            a, b = t32.data_ptr(), t32.data_ptr() + 4 * n
+            g = t.g.images(0, B).ptr if self.ctx.grads else None
+            ops.mse_tap(a, b, n, 1.0 / (n * len(self.taps)), loss, g, 2.0 * weight / (n * len(self.taps)),
+                        accumulate=False)
+
+    def backward(self, dimg: torch.Tensor):
+        """dimg: fp32 (B,1,H,W), += d loss / d prediction image."""
+        B, ctx = self.B, self.ctx
+        for l in reversed(self.layers):
+            if l[0] == "pool":
+                p = l[1]
+                ops.pool_bwd(p.xin.images(0, B).v, p.out.images(0, B).g, p.xin.images(0, B).g, p.mode)
+            else:
+                _, core, bias, out, _t = l
+                o = out.images(0, B)
+                N, Ho, Wo, C = o.shape
+                dpre = ctx.tmp_view(N, Ho, Wo, C)
+                ops.ew(ops.EW_ACTBWD, o.g, dpre, y=o.v, slope=0.0)
+                core.dgrad(dpre, core.xin.images(0, B).g)
+        o = self.a0.images(0, B)
+        dpre = ctx.tmp_view(B, self.H, self.W, 64)
+        ops.ew(ops.EW_ACTBWD, o.g, dpre, y=o.v, slope=0.0)
+        ops.conv_c1_dgrad(dpre, self.w0, dimg, scale=1.0 / 4096.0, accumulate=True)

@@ -68,9 +68,10 @@ def new_view(N: int, H: int, W: int, C: int, device="cuda", zero: bool = False) 
 
 # --------------------------------------------------------------------------- GEMM family
 def conv2d(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed=False, bias=None, act=0,
-           stats=None, accumulate=False, out_f32=False):
+           stats=None, accumulate=False, out_f32=False, y2: Optional[torch.Tensor] = None):
     lib.ried_conv2d(x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C, kh, kw, sh, sw, ph, pw,
-                    int(transposed), _p(bias), act, _p(stats), int(accumulate), int(out_f32), _stream())
+                    int(transposed), _p(bias), act, _p(stats), int(accumulate), int(out_f32), _p(y2), y.C,
+                    _stream())
 
 
 def conv2d_wgrad(g: View, p: View, kh, kw, sh, sw, ph, pw, slab: torch.Tensor, splitk: int):
@@ -170,8 +171,13 @@ def nhwc_to_nchw(x: View, y: torch.Tensor):
     lib.ried_nhwc_to_nchw(x.ptr, x.ld, _p(y), x.N, x.C, x.H * x.W, _stream())
 
 
-def adam(p, g, m, v, lr, step, b1=0.01, b2=0.99, eps=1e-8):
-    lib.ried_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, step, _stream())
+def adam(p, g, m, v, lr, step: torch.Tensor, b1=0.01, b2=0.99, eps=1e-8):
+    """step: int32 device tensor (1,), number of completed steps; incremented by the call."""
+    lib.ried_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, _p(step), _stream())
+
+
+def sum_f32(x: torch.Tensor, n: int, stride: int, scale: float, out: torch.Tensor):
+    lib.ried_sum_f32(_p(x), n, stride, scale, _p(out), _stream())
 
 
 # --------------------------------------------------------------------------- special layers

@@ -1,0 +1,212 @@
+"""The fused G + D + VGG-perceptual + DSSIM training step and the inference + metrics pass.
+
+TrainStep restates the hot loop of the reference's training script (src/train.py:153-177) as one fixed
+sequence of kernel launches over preallocated HBM buffers, captured into a single HIP graph:
+
+    pred = G(x)                                              train.py:153
+    2 x { D(cat[y, pred]); DLoss; D backward; D Adam }       train.py:156-165
+    gloss = CompoundLoss(pred, y, pred_neg of the last D forward)   train.py:172, loss.py:177-197
+    G backward (through D as it was at that forward), G Adam        train.py:176-177
+
+Work the script computes and then discards is not done: the D-loss gradient into G (pred is treated as
+detached in the D iterations), VGG weight gradients, D weight gradients during the G backward.  The script's
+own step raises on torch >= 1.5 (D is updated in place between the forward and the backward that uses it);
+here the G gradient is taken before the last D Adam step, i.e. through the D that produced pred_neg.
+
+Data parallel (one process per GPU, RCCL over xGMI): gradients are averaged with one all-reduce over each
+network's flat gradient buffer; the two hinge means of DLoss are all-reduced before the (non-linear) hinge so
+the result equals the single-GPU step at the same global batch.  BatchNorm statistics stay per replica.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from .engine import Discriminator, Generator, State, Vgg
+
+F32 = torch.float32
+
+# slots of the device scalar array
+SC_MEAN_POS, SC_MEAN_NEG, SC_DLOSS, SC_CPOS, SC_CNEG, SC_VGG, SC_SSIM, SC_DSSIM, SC_GEN, SC_GLOSS = range(10)
+SC_DLOSS1, SC_DLOSS2 = 10, 11
+
+
+class TrainStep:
+    def __init__(self, g_sd: Dict[str, torch.Tensor], d_sd: Dict[str, torch.Tensor], vgg: Dict[str, torch.Tensor],
+                 batch: int, H: int, W: int, lr: float = 1e-4, weights=(0.3, 0.5, 0.2), device="cuda",
+                 use_graph: bool = True, process_group=None):
+        ops.require_gpu()
+        self.B, self.H, self.W, self.lr = batch, H, W, lr
+        self.wv, self.ws, self.wg = weights
+        self.device = device
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None:
+            import torch.distributed as dist
+            self.world = dist.get_world_size(process_group)
+        self.gs, self.ds = State(g_sd, device), State(d_sd, device)
+        B = batch
+        self.G = Generator(self.gs, B, H, W, grads=True, training=True, device=device)
+        self.D = Discriminator(self.ds, 2 * B, H, W, grads=True, training=True, device=device)
+        self.V = Vgg(vgg, B, H, W, grads=True, device=device)
+        self.x = torch.zeros(B, 1, H, W, dtype=F32, device=device)
+        self.y = torch.zeros(B, 1, H, W, dtype=F32, device=device)
+        self.d_in = torch.zeros(2 * B, 1, H, W, dtype=F32, device=device)
+        self.v_in = torch.zeros(2 * B, 1, H, W, dtype=F32, device=device)
+        self.dpred = torch.zeros(B, 1, H, W, dtype=F32, device=device)
+        self.sc = torch.zeros(16, dtype=F32, device=device)
+        self.ssim_sums = torch.zeros(B, 4, dtype=F32, device=device)
+        self.gmap = torch.empty(3, B, H, W, dtype=F32, device=device)
+        self.use_graph = use_graph
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.steps_done = 0
+
+    # ------------------------------------------------------------------ collectives
+    def _allreduce_mean(self, t: torch.Tensor):
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.pg)
+            t.mul_(1.0 / self.world)
+
+    # ------------------------------------------------------------------ the step
+    def _d_iteration(self, last: bool):
+        B, sc, D = self.B, self.sc, self.D
+        out = D.forward(self.d_in)
+        n = out.v.npix // 2 * out.v.C                    # elements per half = B * 8192 at 64x64
+        sc[SC_MEAN_POS:SC_MEAN_NEG + 1].zero_()
+        ops.dot(out.v.images(0, B), None, 1.0 / n, sc[SC_MEAN_POS:])
+        ops.dot(out.v.images(B, 2 * B), None, 1.0 / n, sc[SC_MEAN_NEG:])
+        self._allreduce_mean(sc[SC_MEAN_POS:SC_MEAN_NEG + 1])
+        ops.dloss_scalars(sc, n)
+        sc[SC_DLOSS2 if last else SC_DLOSS1].copy_(sc[SC_DLOSS])
+        D.ctx.zero_backward()
+        self.ds.zero_grad()
+        ops.fill(out.g.images(0, B), 1.0, s=sc[SC_CPOS:])
+        ops.fill(out.g.images(B, 2 * B), 1.0, s=sc[SC_CNEG:])
+        D.backward(0, 2 * B, wgrad=True)
+        self._allreduce_mean(self.ds.flat_grad)
+        if last:
+            self._g_loss_backward(n)
+        self.ds.adam(4.0 * self.lr)
+
+    def _g_loss_backward(self, n: int):
+        B, H, W, sc = self.B, self.H, self.W, self.sc
+        pred, y = self.G.out, self.y
+        self.dpred.zero_()
+        sc[SC_VGG:SC_SSIM + 1].zero_()
+        # perceptual term (loss.py:179-189)
+        self.v_in[:B].copy_(pred)
+        self.v_in[B:].copy_(y)
+        self.V.forward(self.v_in)
+        self.V.ctx.zero_backward()
+        self.V.loss_and_seed(sc[SC_VGG:], self.wv)
+        self.V.backward(self.dpred)
+        # DSSIM term on raw HU (loss.py:191): ssim(target, pred), gradient to pred
+        self.ssim_sums.zero_()
+        ops.ssim_fwd(pred, None, y, 0.01 ** 2, 0.03 ** 2, self.ssim_sums, gmap=self.gmap)
+        ops.sum_f32(self.ssim_sums, B, 4, 1.0 / (B * H * W), sc[SC_SSIM:])
+        ops.ssim_bwd(pred, y, self.gmap, -self.ws * 0.5 / (B * H * W), self.dpred, accumulate=True)
+        # generator term 1 - mean(pred_neg) (loss.py:154-155), through D as it is now
+        out = self.D.out
+        self.D.ctx.zero_backward()
+        ops.fill(out.g.images(B, 2 * B), -self.wg / n)
+        self.D.backward(B, 2 * B, wgrad=False, dimg=self.dpred)
+        ops.gloss_scalars(sc, self.wv, self.ws, self.wg)
+        self.gs.zero_grad()
+        self.G.backward(self.dpred)
+        self._allreduce_mean(self.gs.flat_grad)
+
+    def _body(self):
+        B = self.B
+        pred = self.G.forward(self.x)
+        self.d_in[:B].copy_(self.y)
+        self.d_in[B:].copy_(pred)
+        self._d_iteration(last=False)
+        self._d_iteration(last=True)
+        self.gs.adam(self.lr)
+
+    def step(self, x: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None):
+        """One training iteration on (x, y), fp32 (B,1,H,W) device tensors.  No host synchronisation; read
+        the losses afterwards with losses()."""
+        if x is not None:
+            self.x.copy_(x, non_blocking=True)
+            self.y.copy_(y, non_blocking=True)
+        if not self.use_graph:
+            self._body()
+        else:
+            if self.graph is None:
+                self._capture()
+            self.graph.replay()
+        self.steps_done += 1
+
+    def _capture(self):
+        # one eager step first: it sizes nothing (all buffers exist) but loads every kernel before capture
+        snap = self._snapshot()
+        self._body()
+        torch.cuda.synchronize()
+        self._restore(snap)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._body()
+        self.graph = g
+
+    def _snapshot(self):
+        s = {"g": self.gs.flat.clone(), "d": self.ds.flat.clone(),
+             "gb": {k: v.clone() for k, v in self.gs.b.items()}, "db": {k: v.clone() for k, v in self.ds.b.items()}}
+        return s
+
+    def _restore(self, s):
+        self.gs.flat.copy_(s["g"]); self.ds.flat.copy_(s["d"])
+        for k, v in s["gb"].items():
+            self.gs.b[k].copy_(v)
+        for k, v in s["db"].items():
+            self.ds.b[k].copy_(v)
+        for st in (self.gs, self.ds):
+            st.adam_m.zero_(); st.adam_v.zero_(); st.adam_step.zero_()
+
+    def losses(self) -> Dict[str, float]:
+        """Host read of the last step's scalars (synchronises)."""
+        s = self.sc.clone()
+        if self.world > 1:
+            self._allreduce_mean(s)
+        s = s.cpu()
+        return {"dloss1": s[SC_DLOSS1].item(), "dloss2": s[SC_DLOSS2].item(), "gloss": s[SC_GLOSS].item(),
+                "vgg": s[SC_VGG].item(), "dssim": s[SC_DSSIM].item(), "gen": s[SC_GEN].item(),
+                "ssim": s[SC_SSIM].item()}
+
+
+class InferenceEngine:
+    """The evaluation loop body of the reference (src/test.py:125-144) for a batch of slices: generator forward
+    (train-mode BatchNorm, as the script never calls eval()), clamp to [lo, hi], and the six numbers of
+    measure.compute_measure per slice, from one read of x, y and pred."""
+
+    def __init__(self, g_sd: Dict[str, torch.Tensor], batch: int, H: int, W: int, device="cuda", train_mode_bn=True,
+                 lo=-160.0, hi=240.0):
+        ops.require_gpu()
+        self.gs = State(g_sd, device)
+        self.G = Generator(self.gs, batch, H, W, grads=False, training=train_mode_bn, device=device)
+        self.B, self.H, self.W, self.lo, self.hi = batch, H, W, lo, hi
+        self.sums = torch.zeros(batch, 4, dtype=F32, device=device)
+
+    def run(self, x: torch.Tensor, y: torch.Tensor):
+        """Returns (pred, sums) on the device; sums[n] = [sum ssim(x,y), sum (x-y)^2, sum ssim(pred,y), sum (pred-y)^2]
+        over the clamped images."""
+        pred = self.G.forward(x)
+        dr = self.hi - self.lo
+        self.sums.zero_()
+        ops.ssim_fwd(x, pred, y, (0.01 * dr) ** 2, (0.03 * dr) ** 2, self.sums, clamp=(self.lo, self.hi))
+        return pred, self.sums
+
+    def measures(self, sums: torch.Tensor):
+        """Per-slice ((psnr, ssim, rmse) original, (psnr, ssim, rmse) prediction) as Python floats."""
+        import math
+        s = sums.double().cpu() / (self.H * self.W)
+        dr = self.hi - self.lo
+        out = []
+        for i in range(s.shape[0]):
+            o = (10 * math.log10(dr * dr / s[i, 1].item()), s[i, 0].item(), math.sqrt(s[i, 1].item()))
+            p = (10 * math.log10(dr * dr / s[i, 3].item()), s[i, 2].item(), math.sqrt(s[i, 3].item()))
+            out.append((o, p))
+        return out

@@ -176,14 +176,15 @@ def test_bgemm_asymmetric_identity():
     A = torch.eye(M).unsqueeze(0)
     B = (torch.arange(N * K).reshape(1, N, K) % 251).float()
     out = torch.empty(1, N, M, device=DEV)
-    ops.bgemm(A.to(torch.bfloat16).to(DEV).data_ptr(), K, M * K, 0, B.to(torch.bfloat16).to(DEV).data_ptr(), K, N * K,
-              0, M, N, K, 1, out.data_ptr(), M, N * M, out_f32=True)
+    Ad, Bd = A.to(torch.bfloat16).to(DEV), B.to(torch.bfloat16).to(DEV)     # keep the storages alive
+    ops.bgemm(Ad.data_ptr(), K, M * K, 0, Bd.data_ptr(), K, N * K, 0, M, N, K, 1, out.data_ptr(), M, N * M,
+              out_f32=True)
     assert torch.equal(out.cpu(), torch.einsum("bmk,bnk->bnm", A, B))
 
 
 def test_bn_forward_backward():
     N, C, H = 4, 48, 8
-    x = r(N, C, H, H, seed=16) * 2 + 0.5
+    x = (r(N, C, H, H, seed=16) * 2 + 0.5).to(torch.bfloat16).float()
     gamma, beta = r(C, seed=17) + 1.0, r(C, seed=18) * 0.3
     xr = x.clone().requires_grad_(True)
     g2, b2 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
@@ -280,12 +281,14 @@ def test_adam_matches_torch():
     pd = torch.zeros(1004, device=DEV)[:n]
     pd.copy_(p0)
     m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
     for step in range(1, 4):
         g = torch.randn(n, generator=torch.Generator().manual_seed(10 + step))
         p.grad = g.clone()
         opt.step()
-        ops.adam(pd, g.to(DEV), m, v, 4e-4, step)
+        ops.adam(pd, g.to(DEV), m, v, 4e-4, cnt)
         assert torch.allclose(pd.cpu(), p.detach(), rtol=2e-5, atol=1e-7)
+    assert cnt.item() == 3
 
 
 @pytest.mark.parametrize("cout,stride", [(32, 2), (64, 1)])
@@ -371,7 +374,7 @@ def test_mse_tap_and_loss_scalars():
     a, b = r(n, seed=29), r(n, seed=30)
     loss = torch.zeros(1, device=DEV)
     g = torch.ones(n, dtype=torch.bfloat16, device=DEV)
-    ad, bd = a.to(torch.bfloat16).to(DEV), b.to(torch.bfloat16).to(DEV)
+    ad, bd = a.to(DEV), b.to(DEV)
     ops.mse_tap(ad.data_ptr(), bd.data_ptr(), n, 1.0 / n, loss, g.data_ptr(), 0.25, accumulate=True)
     close(loss.cpu(), ((a - b) ** 2).mean().reshape(1), 1e-4, "mse")
     close(g.float().cpu(), 1.0 + 0.25 * (a - b), what="grad")
