@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Benchmark of the RIED-GAN hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step is one full training iteration (G forward, two D iterations with Adam, VGG16-perceptual + DSSIM + GAN
+generator loss, G backward, G Adam: src/train.py:153-177 of the reference) on a batch of synthetic 1x64x64 HU
+patches per GPU (BASELINE.json configs[1]: batch 128, bf16 storage / fp32 accumulate).  Weak scaling: every
+rank processes its own 128 patches; gradients are averaged with RCCL all-reduces.  Inputs are resident in HBM
+before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra fields
+  roofline      the dominant kernel family (the implicit-GEMM convolution kernel): algorithmic FLOPs of all
+                its launches in one step / their summed duration, measured with HIP events on the launch
+                stream in one eager step after the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
+  cpu_baseline  the CPU oracle (oracle/ried_oracle.py, a port of the reference arithmetic on stock torch CPU
+                ops, fp32) timed on this host's cores on BASELINE.json configs[0] (batch 4 of 1x64x64).
+  infer         512x512 slice inference + SSIM/PSNR/RMSE (configs[2], batch 32), slices/s (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch
+
+PEAK_MFMA_BF16 = 2.5e15        # dense bf16 MFMA peak of one MI355X, FLOP/s
+PEAK_HBM = 8.0e12              # HBM3E peak, B/s
+FLOP_PER_PATCH_64 = 17.716e9   # 3 G + 13 D + 3 VGG forward-equivalents at 64x64 (needed work only)
+
+
+def synth_states(seed=0):
+    from reid_gan_amd import rinet
+    from reid_gan_amd.synth import synth_state, synth_vgg
+    g = synth_state(rinet.state_spec(rinet.RIGAN()), 101 + seed)
+    d = synth_state(rinet.state_spec(rinet.ImageDiscriminator()), 202 + seed)
+    return g, d, synth_vgg()
+
+
+def instrumented_step(ts):
+    """One eager step with HIP events around every launch of the GEMM-family kernels."""
+    from reid_gan_amd import ops
+    rec = []
+    orig = {k: getattr(ops, k) for k in ("conv2d", "conv2d_wgrad", "bgemm")}
+
+    def wrap(name, fn, flops):
+        def inner(*a, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn(*a, **kw)
+            e1.record()
+            rec.append((name, flops(*a, **kw), e0, e1))
+        return inner
+
+    def f_conv(x, w, y, kh, kw_, sh, sw, ph, pw, transposed=False, **k):
+        if transposed:
+            return 2.0 * x.npix * x.C * y.C * kh * kw_
+        return 2.0 * y.npix * y.C * x.C * kh * kw_
+
+    def f_wgrad(g, p, kh, kw_, sh, sw, ph, pw, slab, splitk):
+        return 2.0 * p.npix * p.C * g.C * kh * kw_
+
+    def f_bgemm(A, lda, bsa, a_tr, B, ldb, bsb, b_tr, M, N, K, batch, *a, **k):
+        return 2.0 * M * N * K * batch
+
+    ops.conv2d = wrap("conv", orig["conv2d"], f_conv)
+    ops.conv2d_wgrad = wrap("wgrad", orig["conv2d_wgrad"], f_wgrad)
+    ops.bgemm = wrap("bgemm", orig["bgemm"], f_bgemm)
+    try:
+        ts._run_eager()
+        torch.cuda.synchronize()
+    finally:
+        for k, v in orig.items():
+            setattr(ops, k, v)
+    fam = {}
+    for name, fl, e0, e1 in rec:
+        d = fam.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+        d["launches"] += 1
+        d["flops"] += fl
+        d["ms"] += e0.elapsed_time(e1)
+    return fam
+
+
+def cpu_baseline(budget_s=20.0):
+    from oracle import ried_oracle as O
+    from reid_gan_amd.synth import synth_batch
+    cores = os.cpu_count() or 1
+    cores = min(cores, int(os.environ.get("OMP_NUM_THREADS", cores)))
+    torch.set_num_threads(cores)
+    g, d, vgg = synth_states()
+    x, y = synth_batch(4, 64, seed=1234)
+    st = O.TrainState(g, d, vgg)
+    O.train_step(st, x, y)                       # warm-up
+    t0, n = time.perf_counter(), 0
+    while n < 20 and (time.perf_counter() - t0 < budget_s or n < 2):
+        O.train_step(st, x, y)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": 4 * n / dt, "unit": "patches/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"BASELINE configs[0]: {n} full steps at batch 4 of 1x64x64, fp32, stock torch CPU ops "
+                      f"({dt:.1f} s)"}
+
+
+def infer_bench(steps=5, warmup=2, batch=32, size=512):
+    from reid_gan_amd.synth import synth_batch
+    from reid_gan_amd.train_step import InferenceEngine
+    g, _, _ = synth_states()
+    eng = InferenceEngine(g, batch, size, size)
+    x, y = synth_batch(batch, size, seed=1234)
+    x, y = x.cuda(), y.cuda()
+    for _ in range(warmup):
+        eng.run(x, y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(steps):
+        eng.run(x, y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / steps
+    # metric kernel alone (one read of x, y, pred: 12 B/pixel)
+    from reid_gan_amd import ops
+    pred = eng.G.out
+    m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    m0.record()
+    for _ in range(20):
+        ops.ssim_fwd(x, pred, y, 16.0, 144.0, eng.sums, clamp=(-160.0, 240.0))
+    m1.record()
+    torch.cuda.synchronize()
+    mms = m0.elapsed_time(m1) / 20
+    bytes_alg = batch * size * size * 12.0
+    return {"metric": "512x512 slices/sec (generator inference + SSIM/PSNR/RMSE)", "value": batch / (ms * 1e-3),
+            "unit": "slices/s", "ms_per_batch": ms, "batch": batch,
+            "mfma_frac": batch / (ms * 1e-3) * 34.67e9 / PEAK_MFMA_BF16,
+            "metrics_kernel": {"bound": "hbm", "ms": mms, "achieved": bytes_alg / (mms * 1e-3) / 1e9,
+                               "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": bytes_alg / (mms * 1e-3) / PEAK_HBM}}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="patches per GPU")
+    ap.add_argument("--size", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-infer", action="store_true")
+    args = ap.parse_args()
+
+    from reid_gan_amd import dp
+    from reid_gan_amd.synth import synth_batch
+    from reid_gan_amd.train_step import TrainStep
+    rank, local, world = dp.init_from_env("nccl")
+    if world != args.gpus:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local)
+    import torch.distributed as dist
+    pg = dist.group.WORLD if world > 1 else None
+
+    g, d, vgg = synth_states()
+    ts = TrainStep(g, d, vgg, args.batch, args.size, args.size, lr=1e-4, use_graph=not args.no_graph,
+                   process_group=pg)
+    x, y = synth_batch(args.batch, args.size, seed=1234 + rank)
+    ts.x.copy_(x.cuda())
+    ts.y.copy_(y.cuda())
+    for _ in range(args.warmup):
+        ts.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts.step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    losses = ts.losses()
+    value = world * args.batch * args.steps / dt
+    out = {
+        "metric": "train patches/sec (G+D+VGG step)", "value": value, "unit": "patches/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"BASELINE configs[1]: full RIED-GAN training step, batch {args.batch} of "
+                               f"1x{args.size}x{args.size} patches per GPU, bf16 storage / fp32 accumulate",
+                   "global_batch": world * args.batch, "patch": args.size, "parallelism": f"dp{world}",
+                   "hip_graph": not args.no_graph, "losses": losses},
+    }
+    if args.size == 64:
+        out["step_mfma_frac"] = value / world * FLOP_PER_PATCH_64 / PEAK_MFMA_BF16
+    if rank == 0:
+        fam = instrumented_step(ts)
+        dom = max(fam, key=lambda k: fam[k]["ms"])
+        a = fam[dom]["flops"] / (fam[dom]["ms"] * 1e-3)
+        names = {"conv": "igemm_kernel<*, PLAIN_K, GATHER_K> (conv forward / data gradient)",
+                 "wgrad": "igemm_kernel<*, GATHER_TR, PLAIN_TR> (weight gradient)",
+                 "bgemm": "igemm_kernel<*, PLAIN_*, PLAIN_*> (attention products)"}
+        out["roofline"] = {"bound": "mfma", "kernel": names[dom], "achieved": a / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
+                           "unit": "TFLOP/s", "frac": a / PEAK_MFMA_BF16, "traffic": None,
+                           "launches_per_step": fam[dom]["launches"], "ms_per_step": fam[dom]["ms"],
+                           "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
+                                            "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
+                                        for k, v in fam.items()}}
+    else:
+        ts._run_eager()       # keep the collectives of the instrumented step matched on every rank
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and not args.no_infer:
+            del ts
+            torch.cuda.empty_cache()
+            out["infer"] = infer_bench()
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

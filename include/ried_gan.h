@@ -112,8 +112,10 @@ int ried_nhwc_to_nchw(const void* x, long long ldx, float* y, int nimg, int C, l
  * completed steps, incremented by this call before use (so a captured graph replays correctly). */
 int ried_adam(float* p, const float* g, float* m, float* v, long long n, float lr, float b1, float b2, float eps,
               int* step, ried_stream_t stream);
-/* out[0] += scale * sum_i in[i*stride], i < n  (fp32) */
-int ried_sum_f32(const float* in, long long n, long long stride, float scale, float* out, ried_stream_t stream);
+/* out[0] += scale * sum_i f(in[i*stride]), i < n, f = identity (square = 0) or x^2 (square = 1); fp32.
+ * torch.mean of DLoss / GLoss (src/loss.py:142,155), np.mean / np.std of compute_CNR (src/measure.py:44-45). */
+int ried_sum_f32(const float* in, long long n, long long stride, float scale, int square, float* out,
+                 ried_stream_t stream);
 
 /* ---- one-input-channel 3x3 pad-1 convolutions on the fp32 image ----------------------------------------------- */
 /* generator conv1 (src/rinet.py:55), discriminator layer 0 (:20), VGG16 layer 0 on cat([x,x,x]) (src/loss.py:181)

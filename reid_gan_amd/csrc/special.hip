@@ -514,19 +514,23 @@ extern "C" int ried_fill(void* out, long long ldo, long long npix, int C, const 
   return RIED_OK;
 }
 
-// out[0] += scale * sum_i in[i*stride]
-__global__ void sum_f32_kernel(const float* __restrict__ in, long long n, long long stride, float scale,
+// out[0] += scale * sum_i f(in[i*stride]), f = identity or square
+__global__ void sum_f32_kernel(const float* __restrict__ in, long long n, long long stride, float scale, int square,
                                float* __restrict__ out) {
   __shared__ float sh[4];
   float acc = 0.f;
-  for (long long i = threadIdx.x; i < n; i += blockDim.x) acc += in[i * stride];
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = in[i * stride];
+    acc += square ? v * v : v;
+  }
   float t = block_sum_256(acc, sh);
   if (threadIdx.x == 0) atomicAdd(out, t * scale);
 }
-extern "C" int ried_sum_f32(const float* in, long long n, long long stride, float scale, float* out,
+extern "C" int ried_sum_f32(const float* in, long long n, long long stride, float scale, int square, float* out,
                             hipStream_t stream) {
   RIED_CHECK_ARG(in && out && n > 0 && stride > 0, "ried_sum_f32: bad arguments");
-  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(256), 0, stream, in, n, stride, scale, out);
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(ew_grid(n, 256 * 16, 256)), dim3(256), 0, stream, in, n, stride, scale,
+                     square, out);
   RIED_CHECK_LAUNCH("ried_sum_f32");
   return RIED_OK;
 }

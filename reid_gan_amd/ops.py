@@ -176,8 +176,8 @@ def adam(p, g, m, v, lr, step: torch.Tensor, b1=0.01, b2=0.99, eps=1e-8):
     lib.ried_adam(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, b1, b2, eps, _p(step), _stream())
 
 
-def sum_f32(x: torch.Tensor, n: int, stride: int, scale: float, out: torch.Tensor):
-    lib.ried_sum_f32(_p(x), n, stride, scale, _p(out), _stream())
+def sum_f32(x: torch.Tensor, n: int, stride: int, scale: float, out: torch.Tensor, square: bool = False):
+    lib.ried_sum_f32(_p(x), n, stride, scale, int(square), _p(out), _stream())
 
 
 # --------------------------------------------------------------------------- special layers

@@ -24,6 +24,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
+from .dp import allreduce_mean
 from .engine import Discriminator, Generator, State, Vgg
 
 F32 = torch.float32
@@ -60,17 +61,18 @@ class TrainStep:
         self.ssim_sums = torch.zeros(B, 4, dtype=F32, device=device)
         self.gmap = torch.empty(3, B, H, W, dtype=F32, device=device)
         self.use_graph = use_graph
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.graphs = None          # [(graph, tensor to all-reduce after it or None)]
         self.steps_done = 0
 
     # ------------------------------------------------------------------ collectives
     def _allreduce_mean(self, t: torch.Tensor):
-        if self.world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(t, group=self.pg)
-            t.mul_(1.0 / self.world)
+        allreduce_mean(t, self.pg, self.world)
 
     # ------------------------------------------------------------------ the step
+    # The step is written as a generator that yields the tensors to average across ranks.  With one rank the
+    # yields are skipped and the whole step is one HIP graph; with several ranks each stretch between two
+    # collectives is its own graph and the RCCL all-reduces are issued between the replays on the same stream,
+    # so nothing synchronises with the host either way.
     def _d_iteration(self, last: bool):
         B, sc, D = self.B, self.sc, self.D
         out = D.forward(self.d_in)
@@ -78,7 +80,7 @@ class TrainStep:
         sc[SC_MEAN_POS:SC_MEAN_NEG + 1].zero_()
         ops.dot(out.v.images(0, B), None, 1.0 / n, sc[SC_MEAN_POS:])
         ops.dot(out.v.images(B, 2 * B), None, 1.0 / n, sc[SC_MEAN_NEG:])
-        self._allreduce_mean(sc[SC_MEAN_POS:SC_MEAN_NEG + 1])
+        yield sc[SC_MEAN_POS:SC_MEAN_NEG + 1]            # the hinge acts on the GLOBAL batch means
         ops.dloss_scalars(sc, n)
         sc[SC_DLOSS2 if last else SC_DLOSS1].copy_(sc[SC_DLOSS])
         D.ctx.zero_backward()
@@ -86,9 +88,9 @@ class TrainStep:
         ops.fill(out.g.images(0, B), 1.0, s=sc[SC_CPOS:])
         ops.fill(out.g.images(B, 2 * B), 1.0, s=sc[SC_CNEG:])
         D.backward(0, 2 * B, wgrad=True)
-        self._allreduce_mean(self.ds.flat_grad)
+        yield self.ds.flat_grad
         if last:
-            self._g_loss_backward(n)
+            yield from self._g_loss_backward(n)
         self.ds.adam(4.0 * self.lr)
 
     def _g_loss_backward(self, n: int):
@@ -116,16 +118,20 @@ class TrainStep:
         ops.gloss_scalars(sc, self.wv, self.ws, self.wg)
         self.gs.zero_grad()
         self.G.backward(self.dpred)
-        self._allreduce_mean(self.gs.flat_grad)
+        yield self.gs.flat_grad
 
     def _body(self):
         B = self.B
         pred = self.G.forward(self.x)
         self.d_in[:B].copy_(self.y)
         self.d_in[B:].copy_(pred)
-        self._d_iteration(last=False)
-        self._d_iteration(last=True)
+        yield from self._d_iteration(last=False)
+        yield from self._d_iteration(last=True)
         self.gs.adam(self.lr)
+
+    def _run_eager(self):
+        for t in self._body():
+            self._allreduce_mean(t)
 
     def step(self, x: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None):
         """One training iteration on (x, y), fp32 (B,1,H,W) device tensors.  No host synchronisation; read
@@ -134,23 +140,42 @@ class TrainStep:
             self.x.copy_(x, non_blocking=True)
             self.y.copy_(y, non_blocking=True)
         if not self.use_graph:
-            self._body()
+            self._run_eager()
         else:
-            if self.graph is None:
+            if self.graphs is None:
                 self._capture()
-            self.graph.replay()
+            for g, t in self.graphs:
+                g.replay()
+                if t is not None:
+                    self._allreduce_mean(t)
         self.steps_done += 1
 
     def _capture(self):
-        # one eager step first: it sizes nothing (all buffers exist) but loads every kernel before capture
+        # one eager step first (loads every kernel, warms RCCL), then put the state back
         snap = self._snapshot()
-        self._body()
+        self._run_eager()
         torch.cuda.synchronize()
         self._restore(snap)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._body()
-        self.graph = g
+        graphs = []
+        gen = self._body()
+        pool = None
+        done = False
+        while not done:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool):
+                t = None
+                while True:
+                    try:
+                        t = next(gen)
+                    except StopIteration:
+                        done, t = True, None
+                        break
+                    if self.world > 1:
+                        break                 # close this graph at the collective
+            pool = g.pool()
+            graphs.append((g, t))
+        self.graphs = graphs
+        # the capture pass did not execute anything: state is still the restored one
 
     def _snapshot(self):
         s = {"g": self.gs.flat.clone(), "d": self.ds.flat.clone(),
