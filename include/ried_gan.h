@@ -34,14 +34,17 @@ int ried_device_cus(void);
  * at src/loss.py:74.
  * transposed = 1: ConvTranspose2d forward (src/rinet.py:198) and the data gradient of a Conv2d.
  *   x: view [nimg][H][W] with Cin channels; w: packed bf16 [Cout][kh][kw][Cin]; y: view [nimg][Ho][Wo], Cout.
- *   bias: fp32 [Cout] or NULL; act: 0 none, 1 ReLU, 2 LeakyReLU(0.2); stats: fp32 [2][Cout] accumulated with the
- *   per-channel sum and sum of squares of the fp32 results (for train-mode BatchNorm) or NULL;
+ *   bias: fp32 [Cout] or NULL; act: 0 none, 1 ReLU, 2 LeakyReLU(0.2); stats: NULL, or fp32 [rows][2][Cout] that
+ *   receives one partial (sum, sum of squares) row of the fp32 results per pixel tile, rows =
+ *   ried_conv2d_stat_rows(...) (for train-mode BatchNorm; per-block rows instead of atomics, which serialise);
  *   accumulate: y += result; out_f32: y is fp32 instead of bf16; y2/ldy2: optional second, fp32 copy of the
  *   result (the perceptual-loss taps are compared in fp32) or NULL. */
 int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W, int Cin,
                 int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
                 const float* bias, int act, float* stats, int accumulate, int out_f32, float* y2, long long ldy2,
                 ried_stream_t stream);
+
+int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int sh, int sw, int transposed);
 
 /* Weight-gradient partial sums (autograd of the convs above).  g is the tensor seen through the kernel window
  * (Conv2d: the layer input; ConvTranspose2d: the output gradient), p the tensor indexed by output pixel.
@@ -67,20 +70,21 @@ int ried_pack_weight(const float* src, void* dst, int N, int R, int S, int C, lo
                      long long sc, const float* sigma, ried_stream_t stream);
 
 /* ---- BatchNorm2d, train mode (src/rinet.py:187,199; eps 1e-5, momentum 0.1) ------------------------------------ */
-/* stats [2][C] (sum, sum sq over count values per channel) -> save [2][C] (mean, invstd); updates running stats
- * (unbiased variance) and num_batches_tracked when given. */
-int ried_bn_finalize(const float* stats, int C, long long count, float eps, float momentum, float* save,
+/* stats [nrows][2][C] (partial sum, sum sq rows; count values per channel in all) -> save [2][C] (mean, invstd);
+ * updates running stats (unbiased variance) and num_batches_tracked when given. */
+int ried_bn_finalize(const float* stats, int nrows, int C, long long count, float eps, float momentum, float* save,
                      float* running_mean, float* running_var, long long* num_batches_tracked, ried_stream_t stream);
 int ried_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* save,
                        ried_stream_t stream);
 /* y = [relu](gamma*(x-mean)*invstd + beta) [+ y]   (the residual add of src/rinet.py:250,345,443 is the accumulate) */
 int ried_bn_apply(const void* x, long long ldx, void* y, long long ldy, long long npix, int C, const float* save,
                   const float* gamma, const float* beta, int relu, int accumulate, ried_stream_t stream);
-/* dx = d(loss)/d(conv output) from dy = d(loss)/d(bn+relu output); sums: zeroed fp32 [2][C] scratch;
- * dgamma/dbeta may be NULL. */
+/* dx = d(loss)/d(conv output) from dy = d(loss)/d(bn+relu output); scratch: fp32
+ * [ried_bn_backward_scratch_floats(C)] (need not be zeroed); dgamma/dbeta may be NULL. */
 int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
                      long long npix, int C, const float* save, const float* gamma, const float* beta, int relu,
-                     float* sums, float* dgamma, float* dbeta, int accumulate, ried_stream_t stream);
+                     float* scratch, float* dgamma, float* dbeta, int accumulate, ried_stream_t stream);
+long long ried_bn_backward_scratch_floats(int C);
 
 /* ---- pooling / upsampling ------------------------------------------------------------------------------------- */
 /* mode 0: MaxPool2d(3,2,1) (src/rinet.py:260,355); 1: MaxPool2d(2,2) (VGG16); 2: avg_pool2d(3,1,1) (:235,330,428) */
@@ -99,7 +103,9 @@ int ried_upsample2x_bwd(const void* dy, long long lddy, void* dx, long long lddx
  * act'(y) = y>0 ? 1 : slope, taken from the activation OUTPUT y (ReLU: slope 0; LeakyReLU: 0.2). */
 int ried_ew(int op, const void* a, long long lda, const void* y, long long ldy, void* out, long long ldo,
             long long npix, int C, float slope, const float* s, ried_stream_t stream);
-int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, ried_stream_t stream); /* out[c] += */
+/* out[c] += sum_p a[p][c]; scratch: fp32 [ried_colsum_scratch_floats(C)] */
+int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, float* scratch, ried_stream_t stream);
+long long ried_colsum_scratch_floats(int C);
 int ried_dot(const void* a, long long lda, const void* b, long long ldb, long long npix, int C, float scale, float* out,
              ried_stream_t stream); /* out[0] += scale * sum a*b (b NULL: sum a) */
 int ried_fill(void* out, long long ldo, long long npix, int C, const float* s, float value, ried_stream_t stream);
@@ -123,9 +129,12 @@ int ried_sum_f32(const float* in, long long n, long long stride, float scale, in
  * the input is used as x*in_scale + in_shift (normalize_, src/loss.py:20-22), zero padded after the affine. */
 int ried_conv_c1_fwd(const float* x, const float* w, const float* sigma, const float* bias, void* y, long long ldy,
                      int nimg, int H, int W, int Cout, int stride, float in_scale, float in_shift, int act,
-                     float* stats, ried_stream_t stream);
+                     float* stats, ried_stream_t stream); /* stats: NULL or [ried_conv_c1_stat_rows(..)][2][Cout] */
+int ried_conv_c1_stat_rows(int nimg, int H, int W, int Cout, int stride);
+/* dw[Cout][9] += ; scratch: fp32 [ried_conv_c1_wgrad_scratch_floats(Cout)] */
 int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy, int nimg, int H, int W, int Cout, int stride,
-                       float in_scale, float in_shift, float* dw, ried_stream_t stream); /* dw[Cout][9] += */
+                       float in_scale, float in_shift, float* dw, float* scratch, ried_stream_t stream);
+long long ried_conv_c1_wgrad_scratch_floats(int Cout);
 int ried_conv_c1_dgrad(const void* dy, long long lddy, const float* w, const float* sigma, float* dx, int nimg, int H,
                        int W, int Cout, float scale, int accumulate, ried_stream_t stream); /* stride 1 */
 
@@ -137,7 +146,7 @@ int ried_out_conv_bwd(const float* x, const void* h, long long ldh, const float*
 
 /* ---- spectral norm (torch/nn/utils/spectral_norm.py:97-113 as used at src/rinet.py:138) ------------------------ */
 /* Wm: weight_orig as fp32 [R][K].  power_iter = 1 updates u [R] and v [K] in place, then sigma[0] = u.(W v).
- * scratch: fp32 [K + R + 2]. */
+ * scratch: fp32 [K + R]. */
 int ried_sn_sigma(const float* Wm, int R, int K, float* u, float* v, float* sigma, float* scratch, int power_iter,
                   float eps, ried_stream_t stream);
 /* dW (+)= (dWsn - (sum(dWsn*W)/sigma) u v^T)/sigma ; scratch1: one fp32 */

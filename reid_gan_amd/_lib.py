@@ -28,7 +28,7 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[str, List[Tuple[str
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
     protos = {}
-    for m in re.finditer(r"(const char\*|int)\s+(ried_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"(const char\*|long long|int)\s+(ried_\w+)\s*\(([^;{}]*?)\)\s*;", src, flags=re.S):
         ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
         out = []
         if args and args != "void":
@@ -47,6 +47,9 @@ def _ctype_of(t: str):
     return _CTYPES[t]
 
 
+_VALUE_SUFFIXES = ("_rows", "_floats", "_version", "_cus")
+
+
 class _Lib:
     def __init__(self):
         self._dll = None
@@ -61,7 +64,8 @@ class _Lib:
             dll = ctypes.CDLL(LIB_PATH)
             for name, (ret, args) in self.protos.items():
                 fn = getattr(dll, name)          # AttributeError if the header declares what the .so lacks
-                fn.restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+                fn.restype = (ctypes.c_char_p if "char" in ret else
+                              ctypes.c_longlong if ret == "long long" else ctypes.c_int)
                 fn.argtypes = [_ctype_of(t) for t, _ in args]
             self._dll = dll
         return self._dll
@@ -69,6 +73,8 @@ class _Lib:
     def call(self, name: str, *args):
         dll = self.load()
         rc = getattr(dll, name)(*args)
+        if name.endswith(_VALUE_SUFFIXES):       # size / count queries return their value, not a status
+            return rc
         if rc != 0:
             msg = dll.ried_last_error()
             raise RuntimeError(f"{name} failed ({rc}): {msg.decode() if msg else '?'}")

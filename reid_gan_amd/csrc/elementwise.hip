@@ -93,14 +93,37 @@ extern "C" int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp
 // ---------------------------------------------------------------------------
 // BatchNorm2d, train mode (reference: src/rinet.py:187-193,199-205; torch semantics, eps 1e-5, momentum 0.1)
 // ---------------------------------------------------------------------------
-// stats: [2][C] sum, sum of squares (from the conv epilogue).  save: [2][C] mean, invstd.
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, float count, float eps, float momentum,
-                                   float* __restrict__ save, float* __restrict__ running_mean,
+// Sum over rows of a [nrows][2][C] fp32 buffer for 32 channels per block: 256 threads = 32 channels x 8 row lanes.
+// Returns (sum, sum2) for channel c in the threads with ty == 0.
+__device__ __forceinline__ void reduce_rows_2c(const float* __restrict__ part, int nrows, int C, int c, int ty,
+                                               float& s0, float& s1, float (*sh)[8][32]) {
+  float a = 0.f, b = 0.f;
+  if (c < C)
+    for (int r = ty; r < nrows; r += 8) {
+      a += part[(long long)r * 2 * C + c];
+      b += part[(long long)r * 2 * C + C + c];
+    }
+  sh[0][ty][threadIdx.x & 31] = a;
+  sh[1][ty][threadIdx.x & 31] = b;
+  __syncthreads();
+  s0 = 0.f; s1 = 0.f;
+  if (ty == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { s0 += sh[0][k][threadIdx.x & 31]; s1 += sh[1][k][threadIdx.x & 31]; }
+  }
+}
+
+// stats: [nrows][2][C] per-block partial sum / sum of squares from the conv epilogue.  save: [2][C] mean, invstd.
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nrows, int C, float count, float eps,
+                                   float momentum, float* __restrict__ save, float* __restrict__ running_mean,
                                    float* __restrict__ running_var, long long* __restrict__ nbt) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) {
-    float mean = stats[c] / count;
-    float var = fmaxf(stats[C + c] / count - mean * mean, 0.f);
+  __shared__ float sh[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
+  float s0, s1;
+  reduce_rows_2c(stats, nrows, C, c, ty, s0, s1, sh);
+  if (ty == 0 && c < C) {
+    float mean = s0 / count;
+    float var = fmaxf(s1 / count - mean * mean, 0.f);
     save[c] = mean;
     save[C + c] = rsqrtf(var + eps);
     if (running_mean) {
@@ -109,15 +132,15 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int C, float
       running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
     }
   }
-  if (c == 0 && nbt) nbt[0] += 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
 }
 
-extern "C" int ried_bn_finalize(const float* stats, int C, long long count, float eps, float momentum, float* save,
-                                float* running_mean, float* running_var, long long* num_batches_tracked,
-                                hipStream_t stream) {
-  RIED_CHECK_ARG(stats && save && C > 0 && count > 0, "ried_bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, stats, C, (float)count, eps,
-                     momentum, save, running_mean, running_var, num_batches_tracked);
+extern "C" int ried_bn_finalize(const float* stats, int nrows, int C, long long count, float eps, float momentum,
+                                float* save, float* running_mean, float* running_var,
+                                long long* num_batches_tracked, hipStream_t stream) {
+  RIED_CHECK_ARG(stats && save && C > 0 && count > 0 && nrows > 0, "ried_bn_finalize: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, stream, stats, nrows, C, (float)count,
+                     eps, momentum, save, running_mean, running_var, num_batches_tracked);
   RIED_CHECK_LAUNCH("ried_bn_finalize");
   return RIED_OK;
 }
@@ -210,7 +233,8 @@ __global__ void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, long long ld
     for (int q = 0; q < 8; ++q) { atomicAdd(&lsum[c + q], s1[q]); atomicAdd(&lsum[C + c + q], s2[q]); }
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) atomicAdd(&sums[j], lsum[j]);
+  float* row = sums + (long long)blockIdx.x * 2 * C;            // one partial row per block, no global atomics
+  for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) row[j] = lsum[j];
 }
 
 // backward pass 2: dx = gamma*invstd*(g - s1/n - xhat*s2/n)
@@ -240,37 +264,47 @@ __global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, long long ldd
   }
 }
 
-__global__ void bn_param_grad_kernel(const float* sums, int C, float* dgamma, float* dbeta, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) {
-    dbeta[c] = accumulate ? dbeta[c] + sums[c] : sums[c];
-    dgamma[c] = accumulate ? dgamma[c] + sums[C + c] : sums[C + c];
+// partial rows [nrows][2][C] -> final sums [2][C] (read by the apply pass) and the parameter gradients
+__global__ void bn_bwd_finish_kernel(const float* __restrict__ part, int nrows, int C, float* __restrict__ fin,
+                                     float* dgamma, float* dbeta, int accumulate) {
+  __shared__ float sh[2][8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
+  float s0, s1;
+  reduce_rows_2c(part, nrows, C, c, ty, s0, s1, sh);
+  if (ty == 0 && c < C) {
+    fin[c] = s0; fin[C + c] = s1;
+    if (dgamma) {
+      dbeta[c] = accumulate ? dbeta[c] + s0 : s0;
+      dgamma[c] = accumulate ? dgamma[c] + s1 : s1;
+    }
   }
 }
 
-// sums must be zero on entry ([2][C] fp32).  dgamma/dbeta may be null (no parameter gradient wanted).
+#define BN_BWD_MAX_ROWS 256
+// scratch: fp32 [(BN_BWD_MAX_ROWS + 1) * 2 * C] (need not be zeroed).  dgamma/dbeta may be null.
 extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
                                 long long npix, int C, const float* save, const float* gamma, const float* beta,
-                                int relu, float* sums, float* dgamma, float* dbeta, int accumulate,
+                                int relu, float* scratch, float* dgamma, float* dbeta, int accumulate,
                                 hipStream_t stream) {
   CHECK_VIEW("ried_bn_backward", dy, lddy, C);
   CHECK_VIEW("ried_bn_backward", x, ldx, C);
   CHECK_VIEW("ried_bn_backward", dx, lddx, C);
-  RIED_CHECK_ARG(save && gamma && beta && sums && npix > 0, "ried_bn_backward: bad arguments");
+  RIED_CHECK_ARG(save && gamma && beta && scratch && npix > 0, "ried_bn_backward: bad arguments");
   RIED_CHECK_ARG(C <= 4096, "ried_bn_backward: C too large");
-  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, 1024);
+  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, BN_BWD_MAX_ROWS);
   if (grid * EW_THREADS < C / 8) grid = ceil_div(C / 8, EW_THREADS);
+  float* fin = scratch + (long long)BN_BWD_MAX_ROWS * 2 * C;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), 2 * C * sizeof(float), stream,
-                     (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, sums);
-  if (dgamma && dbeta)
-    hipLaunchKernelGGL(bn_param_grad_kernel, dim3(ceil_div(C, 256)), dim3(256), 0, stream, sums, C, dgamma, dbeta,
-                       accumulate);
+                     (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, scratch);
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, stream, scratch, grid, C, fin,
+                     (dgamma && dbeta) ? dgamma : nullptr, dbeta, accumulate);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS)), dim3(EW_THREADS), 0, stream,
                      (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (bf16_t*)dx, lddx, npix, C, save, gamma, beta,
-                     relu, sums);
+                     relu, fin);
   RIED_CHECK_LAUNCH("ried_bn_backward");
   return RIED_OK;
 }
+extern "C" long long ried_bn_backward_scratch_floats(int C) { return (long long)(BN_BWD_MAX_ROWS + 1) * 2 * C; }
 
 // ---------------------------------------------------------------------------
 // pooling / upsampling (reference: src/rinet.py:235,260,266,330,355,361,428; VGG16 MaxPool2d(2,2))
@@ -576,9 +610,9 @@ extern "C" int ried_ew(int op, const void* a, long long lda, const void* y, long
   return RIED_OK;
 }
 
-// column sums: out[c] (+)= scale * sum_p a[p][c]     (bias gradients)
+// column sums (bias gradients): per-block partial rows, then a row reduction; no global atomics
 __global__ void colsum_kernel(const bf16_t* __restrict__ a, long long lda, long long npix, int C,
-                              float* __restrict__ out) {
+                              float* __restrict__ part) {
   extern __shared__ float lsum[];
   for (int i = threadIdx.x; i < C; i += blockDim.x) lsum[i] = 0.f;
   __syncthreads();
@@ -602,20 +636,39 @@ __global__ void colsum_kernel(const bf16_t* __restrict__ a, long long lda, long 
     for (int q = 0; q < 8; ++q) atomicAdd(&lsum[c + q], s[q]);
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < C; j += blockDim.x) atomicAdd(&out[j], lsum[j]);
+  for (int j = threadIdx.x; j < C; j += blockDim.x) part[(long long)blockIdx.x * C + j] = lsum[j];
+}
+__global__ void colsum_finish_kernel(const float* __restrict__ part, int nrows, int C, float* __restrict__ out) {
+  __shared__ float sh[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
+  float a = 0.f;
+  if (c < C)
+    for (int r = ty; r < nrows; r += 8) a += part[(long long)r * C + c];
+  sh[ty][threadIdx.x & 31] = a;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x & 31];
+    out[c] += t;
+  }
 }
 
-// out must hold the value to accumulate onto (zero it first for a plain sum)
-extern "C" int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, hipStream_t stream) {
+#define COLSUM_MAX_ROWS 256
+// out[c] += sum_p a[p][c].  scratch: fp32 [COLSUM_MAX_ROWS * C].
+extern "C" int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, float* scratch,
+                           hipStream_t stream) {
   CHECK_VIEW("ried_colsum", a, lda, C);
-  RIED_CHECK_ARG(out && npix > 0 && C <= 8192, "ried_colsum: bad arguments");
-  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, 512);
+  RIED_CHECK_ARG(out && scratch && npix > 0 && C <= 8192, "ried_colsum: bad arguments");
+  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, COLSUM_MAX_ROWS);
   if (grid * EW_THREADS < C / 8) grid = ceil_div(C / 8, EW_THREADS);
-  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(EW_THREADS),
-                     C * sizeof(float), stream, (const bf16_t*)a, lda, npix, C, out);
+  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(EW_THREADS), C * sizeof(float), stream, (const bf16_t*)a, lda,
+                     npix, C, scratch);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, stream, scratch, grid, C, out);
   RIED_CHECK_LAUNCH("ried_colsum");
   return RIED_OK;
 }
+extern "C" long long ried_colsum_scratch_floats(int C) { return (long long)COLSUM_MAX_ROWS * C; }
 
 // ---------------------------------------------------------------------------
 // softmax over the last dimension (reference: src/rinet.py:174) and its backward
@@ -699,7 +752,7 @@ extern "C" int ried_dot(const void* a, long long lda, const void* b, long long l
   CHECK_VIEW("ried_dot", a, lda, C);
   if (b) CHECK_VIEW("ried_dot", b, ldb, C);
   RIED_CHECK_ARG(out && npix > 0, "ried_dot: bad arguments");
-  hipLaunchKernelGGL(dot_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS * 4, 512)), dim3(EW_THREADS), 0, stream,
+  hipLaunchKernelGGL(dot_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS * 4, 128)), dim3(EW_THREADS), 0, stream,
                      (const bf16_t*)a, lda, (const bf16_t*)b, ldb, npix, C, scale, out);
   RIED_CHECK_LAUNCH("ried_dot");
   return RIED_OK;

@@ -435,7 +435,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
     }
   }
   if (E.stats) {
-    // rows n that are out of range were loaded as zeros, so they add nothing.
+    // Per-block partial sums, one row of [2][M] per (phase, pixel tile): same-address float atomics serialise at
+    // about 0.1 us each on this part, which at thousands of blocks would dwarf the convolution itself.
+    // Rows n that are out of range were loaded as zeros, so they add nothing.
+    float* red = reinterpret_cast<float*>(smem);          // [2][BM]; the k loop ended with a barrier
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -443,14 +446,41 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
         float a = ssum[i][q], b = ssq[i][q];
 #pragma unroll
         for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
-        if ((lane & 15) == 0 && m < P.M) {
-          atomicAdd(E.stats + m, a);
-          atomicAdd(E.stats + P.M + m, b);
-        }
+        ssum[i][q] = a; ssq[i][q] = b;
       }
     }
+    if (wn == 1 && (lane & 15) == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int ml = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
+          red[ml] = ssum[i][q]; red[BM + ml] = ssq[i][q];
+        }
+    }
+    __syncthreads();
+    if (wn == 0 && (lane & 15) == 0) {
+      float* row = E.stats + ((long long)blockIdx.y * gridDim.x / P.tiles_m + tn) * 2 * P.M;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int ml = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
+          int m = m0 + ml;
+          if (m < P.M) {
+            row[m] = ssum[i][q] + red[ml];
+            row[P.M + m] = ssq[i][q] + red[BM + ml];
+          }
+        }
+    }
   }
+}
+
+// rows of the partial-statistics buffer a ried_conv2d call with stats writes: [rows][2][Cout]
+extern "C" int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int sh, int sw, int transposed) {
+  long long npix = transposed ? (long long)nimg * (Ho / sh) * (Wo / sw) : (long long)nimg * Ho * Wo;
+  int phases = transposed ? sh * sw : 1;
+  return phases * ceil_div(npix, 128);
 }
 
 // ---------------------------------------------------------------------------

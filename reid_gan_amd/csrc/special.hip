@@ -18,6 +18,25 @@ __device__ __forceinline__ void unpack8s(const u32x4& v, float (&f)[8]) {
 // 3x3, pad 1, one input channel (fp32 image), stride 1 or 2
 // ---------------------------------------------------------------------------
 // y[p][co] = act( sum_t w[co][t] * (xin*in_scale + in_shift)[p@t] / sigma + bias[co] ), zero padding after the affine.
+// A thread owns 8 output channels (its 72 weights live in registers) and walks pixels p, p + step, ...; the pixel
+// coordinates advance by a precomputed mixed-radix step, so the loop has no integer division.
+struct PixelWalk {
+  int n, y, x;        // current (image, row, column)
+  int dn, dy, dx;     // step, as whole images + rows + columns
+  int Ho, Wo;
+  __device__ __forceinline__ void init(long long p, long long step, int Ho_, int Wo_) {
+    Ho = Ho_; Wo = Wo_;
+    long long hw = (long long)Ho * Wo;
+    n = (int)(p / hw); int r = (int)(p - (long long)n * hw); y = r / Wo; x = r - y * Wo;
+    dn = (int)(step / hw); int r2 = (int)(step - (long long)dn * hw); dy = r2 / Wo; dx = r2 - dy * Wo;
+  }
+  __device__ __forceinline__ void next() {
+    x += dx; y += dy; n += dn;
+    if (x >= Wo) { x -= Wo; ++y; }
+    if (y >= Ho) { y -= Ho; ++n; }
+  }
+};
+
 template <int COUT>
 __global__ __launch_bounds__(SP_THREADS) void conv_c1_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sigma,
@@ -25,37 +44,42 @@ __global__ __launch_bounds__(SP_THREADS) void conv_c1_fwd_kernel(
     int stride, float in_scale, float in_shift, int act, float* __restrict__ stats) {
   constexpr int CC = COUT / 8;
   constexpr int PPB = SP_THREADS / CC;              // pixels per block pass
-  __shared__ float wl[9][COUT];
   __shared__ float lst[2][COUT];
   const float inv = sigma ? 1.f / sigma[0] : 1.f;
-  for (int i = threadIdx.x; i < 9 * COUT; i += SP_THREADS) wl[i % 9][i / 9] = w[i] * inv;
   if (stats) for (int i = threadIdx.x; i < 2 * COUT; i += SP_THREADS) (&lst[0][0])[i] = 0.f;
   __syncthreads();
   const int c = (threadIdx.x % CC) * 8;
   const int pl = threadIdx.x / CC;
+  float wr[9][8], bq[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    bq[q] = bias ? bias[c + q] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wr[t][q] = w[(c + q) * 9 + t] * inv;
+  }
   const long long npix = (long long)nimg * Ho * Wo;
+  const long long step = (long long)gridDim.x * PPB;
   float s1[8], s2[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
-  for (long long p = (long long)blockIdx.x * PPB + pl; p < npix; p += (long long)gridDim.x * PPB) {
-    int ox = (int)(p % Wo);
-    long long t = p / Wo;
-    int oy = (int)(t % Ho);
-    int n = (int)(t / Ho);
+  long long p = (long long)blockIdx.x * PPB + pl;
+  PixelWalk pw;
+  pw.init(p, step, Ho, Wo);
+  for (; p < npix; p += step, pw.next()) {
     float acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    const float* xi = x + (long long)n * H * W;
+    const float* xi = x + (long long)pw.n * H * W;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      int hi = oy * stride - 1 + r;
+      int hi = pw.y * stride - 1 + r;
 #pragma unroll
       for (int z = 0; z < 3; ++z) {
-        int wi = ox * stride - 1 + z;
+        int wi = pw.x * stride - 1 + z;
         bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
         float v = ok ? xi[(long long)hi * W + wi] * in_scale + in_shift : 0.f;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += v * wl[r * 3 + z][c + q];
+        for (int q = 0; q < 8; ++q) acc[q] += v * wr[r * 3 + z][q];
       }
     }
     if (stats) {
@@ -64,7 +88,7 @@ __global__ __launch_bounds__(SP_THREADS) void conv_c1_fwd_kernel(
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = acc[q] + (bias ? bias[c + q] : 0.f);
+      float v = acc[q] + bq[q];
       if (act == 1) v = fmaxf(v, 0.f);
       else if (act == 2) v = v > 0.f ? v : 0.2f * v;
       acc[q] = v;
@@ -76,8 +100,13 @@ __global__ __launch_bounds__(SP_THREADS) void conv_c1_fwd_kernel(
 #pragma unroll
     for (int q = 0; q < 8; ++q) { atomicAdd(&lst[0][c + q], s1[q]); atomicAdd(&lst[1][c + q], s2[q]); }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * COUT; i += SP_THREADS) atomicAdd(&stats[i], (&lst[0][0])[i]);
+    float* row = stats + (long long)blockIdx.x * 2 * COUT;        // one partial row per block (no global atomics)
+    for (int i = threadIdx.x; i < 2 * COUT; i += SP_THREADS) row[i] = (&lst[0][0])[i];
   }
+}
+
+static int c1_fwd_grid(long long npix, int Cout, bool stats) {
+  return ew_grid(npix, (SP_THREADS / (Cout / 8)) * 2, stats ? 1024 : 4096);
 }
 
 extern "C" int ried_conv_c1_fwd(const float* x, const float* w, const float* sigma, const float* bias, void* y,
@@ -86,30 +115,33 @@ extern "C" int ried_conv_c1_fwd(const float* x, const float* w, const float* sig
   RIED_CHECK_ARG(x && w && y && nimg > 0 && H > 0 && W > 0, "ried_conv_c1_fwd: bad arguments");
   RIED_CHECK_ARG(stride == 1 || stride == 2, "ried_conv_c1_fwd: stride must be 1 or 2");
   RIED_CHECK_ARG(ldy % 8 == 0 && ldy >= Cout && ((uintptr_t)y % 16) == 0, "ried_conv_c1_fwd: output view");
+  RIED_CHECK_ARG(Cout == 32 || Cout == 64, "ried_conv_c1_fwd: Cout must be 32 or 64 (got %d)", Cout);
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   long long npix = (long long)nimg * Ho * Wo;
-  if (Cout == 32) {
-    int grid = ew_grid(npix, SP_THREADS / 4 * 4, 2048);
+  int grid = c1_fwd_grid(npix, Cout, stats != nullptr);
+  if (Cout == 32)
     hipLaunchKernelGGL(conv_c1_fwd_kernel<32>, dim3(grid), dim3(SP_THREADS), 0, stream, x, w, sigma, bias,
                        (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats);
-  } else if (Cout == 64) {
-    int grid = ew_grid(npix, SP_THREADS / 8 * 4, 2048);
+  else
     hipLaunchKernelGGL(conv_c1_fwd_kernel<64>, dim3(grid), dim3(SP_THREADS), 0, stream, x, w, sigma, bias,
                        (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats);
-  } else {
-    RIED_CHECK_ARG(false, "ried_conv_c1_fwd: Cout must be 32 or 64 (got %d)", Cout);
-  }
   RIED_CHECK_LAUNCH("ried_conv_c1_fwd");
   return RIED_OK;
 }
 
-// dw[co][t] += sum_p dy[p][co] * xaff[p@t]      (fp32 atomics onto a zeroed / accumulating [Cout][9] buffer)
+// rows of the partial-statistics buffer ([rows][2][Cout]) that ried_conv_c1_fwd writes when stats is given
+extern "C" int ried_conv_c1_stat_rows(int nimg, int H, int W, int Cout, int stride) {
+  int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
+  return c1_fwd_grid((long long)nimg * Ho * Wo, Cout, true);
+}
+
+// part[block][co][t] = sum over the block's pixels of dy[p][co] * xaff[p@t]; a second kernel adds the rows into dw
 template <int COUT>
 __global__ __launch_bounds__(SP_THREADS) void conv_c1_wgrad_kernel(const float* __restrict__ x,
                                                                    const bf16_t* __restrict__ dy, long long lddy,
                                                                    int nimg, int H, int W, int Ho, int Wo, int stride,
                                                                    float in_scale, float in_shift,
-                                                                   float* __restrict__ dw) {
+                                                                   float* __restrict__ part) {
   constexpr int CC = COUT / 8;
   constexpr int PPB = SP_THREADS / CC;
   __shared__ float ldw[COUT * 9];
@@ -118,25 +150,26 @@ __global__ __launch_bounds__(SP_THREADS) void conv_c1_wgrad_kernel(const float* 
   const int c = (threadIdx.x % CC) * 8;
   const int pl = threadIdx.x / CC;
   const long long npix = (long long)nimg * Ho * Wo;
+  const long long step = (long long)gridDim.x * PPB;
   float acc[8][9];
 #pragma unroll
   for (int q = 0; q < 8; ++q)
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[q][t] = 0.f;
-  for (long long p = (long long)blockIdx.x * PPB + pl; p < npix; p += (long long)gridDim.x * PPB) {
-    int ox = (int)(p % Wo);
-    long long t2 = p / Wo;
-    int oy = (int)(t2 % Ho);
-    int n = (int)(t2 / Ho);
+  long long p = (long long)blockIdx.x * PPB + pl;
+  PixelWalk pw;
+  pw.init(p, step, Ho, Wo);
+#pragma unroll 2
+  for (; p < npix; p += step, pw.next()) {
     float g[8];
     unpack8s(*reinterpret_cast<const u32x4*>(dy + p * lddy + c), g);
-    const float* xi = x + (long long)n * H * W;
+    const float* xi = x + (long long)pw.n * H * W;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
-      int hi = oy * stride - 1 + r;
+      int hi = pw.y * stride - 1 + r;
 #pragma unroll
       for (int z = 0; z < 3; ++z) {
-        int wi = ox * stride - 1 + z;
+        int wi = pw.x * stride - 1 + z;
         bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
         float v = ok ? xi[(long long)hi * W + wi] * in_scale + in_shift : 0.f;
 #pragma unroll
@@ -149,28 +182,49 @@ __global__ __launch_bounds__(SP_THREADS) void conv_c1_wgrad_kernel(const float* 
 #pragma unroll
     for (int t = 0; t < 9; ++t) atomicAdd(&ldw[(c + q) * 9 + t], acc[q][t]);
   __syncthreads();
-  for (int i = threadIdx.x; i < COUT * 9; i += SP_THREADS) atomicAdd(&dw[i], ldw[i]);
+  float* row = part + (long long)blockIdx.x * COUT * 9;
+  for (int i = threadIdx.x; i < COUT * 9; i += SP_THREADS) row[i] = ldw[i];
 }
 
+__global__ void rows_add_kernel(const float* __restrict__ part, int nrows, int Wd, float* __restrict__ out) {
+  __shared__ float sh[8][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
+  float a = 0.f;
+  if (c < Wd)
+    for (int r = ty; r < nrows; r += 8) a += part[(long long)r * Wd + c];
+  sh[ty][threadIdx.x & 31] = a;
+  __syncthreads();
+  if (ty == 0 && c < Wd) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x & 31];
+    out[c] += t;
+  }
+}
+
+#define C1_WGRAD_MAX_ROWS 512
+// dw[Cout][9] += weight gradient.  scratch: fp32 [ried_conv_c1_wgrad_scratch_floats(Cout)].
 extern "C" int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy, int nimg, int H, int W, int Cout,
-                                  int stride, float in_scale, float in_shift, float* dw, hipStream_t stream) {
-  RIED_CHECK_ARG(x && dy && dw && nimg > 0, "ried_conv_c1_wgrad: bad arguments");
+                                  int stride, float in_scale, float in_shift, float* dw, float* scratch,
+                                  hipStream_t stream) {
+  RIED_CHECK_ARG(x && dy && dw && scratch && nimg > 0, "ried_conv_c1_wgrad: bad arguments");
   RIED_CHECK_ARG(stride == 1 || stride == 2, "ried_conv_c1_wgrad: stride must be 1 or 2");
   RIED_CHECK_ARG(lddy % 8 == 0 && lddy >= Cout && ((uintptr_t)dy % 16) == 0, "ried_conv_c1_wgrad: dy view");
+  RIED_CHECK_ARG(Cout == 32 || Cout == 64, "ried_conv_c1_wgrad: Cout must be 32 or 64");
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   long long npix = (long long)nimg * Ho * Wo;
-  int grid = ew_grid(npix, 64 * 16, 512);
+  int grid = ew_grid(npix, (SP_THREADS / (Cout / 8)) * 8, C1_WGRAD_MAX_ROWS);
   if (Cout == 32)
     hipLaunchKernelGGL(conv_c1_wgrad_kernel<32>, dim3(grid), dim3(SP_THREADS), 0, stream, x, (const bf16_t*)dy, lddy,
-                       nimg, H, W, Ho, Wo, stride, in_scale, in_shift, dw);
-  else if (Cout == 64)
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel<64>, dim3(grid), dim3(SP_THREADS), 0, stream, x, (const bf16_t*)dy, lddy,
-                       nimg, H, W, Ho, Wo, stride, in_scale, in_shift, dw);
+                       nimg, H, W, Ho, Wo, stride, in_scale, in_shift, scratch);
   else
-    RIED_CHECK_ARG(false, "ried_conv_c1_wgrad: Cout must be 32 or 64");
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel<64>, dim3(grid), dim3(SP_THREADS), 0, stream, x, (const bf16_t*)dy, lddy,
+                       nimg, H, W, Ho, Wo, stride, in_scale, in_shift, scratch);
+  hipLaunchKernelGGL(rows_add_kernel, dim3(ceil_div(Cout * 9, 32)), dim3(256), 0, stream, scratch, grid, Cout * 9, dw);
   RIED_CHECK_LAUNCH("ried_conv_c1_wgrad");
   return RIED_OK;
 }
+extern "C" long long ried_conv_c1_wgrad_scratch_floats(int Cout) { return (long long)C1_WGRAD_MAX_ROWS * Cout * 9; }
 
 // stride 1 data gradient: dx[h][w] (+)= scale * sum_{co,r,s} dy[h+1-r][w+1-s][co] * w[co][r][s] / sigma
 // 8 lanes per pixel (one 8-channel chunk each), reduced with shuffles.
@@ -300,7 +354,7 @@ extern "C" int ried_out_conv_bwd(const float* x, const void* h, long long ldh, c
                                  void* dh, long long lddh, float* dw, long long npix, hipStream_t stream) {
   RIED_CHECK_ARG(x && h && w && dout && dh && dw && npix > 0 && ldh % 8 == 0 && lddh % 8 == 0 &&
                      ((uintptr_t)h % 16) == 0 && ((uintptr_t)dh % 16) == 0, "ried_out_conv_bwd: bad arguments");
-  hipLaunchKernelGGL(out_conv_bwd_kernel, dim3(ew_grid(npix * 4, SP_THREADS * 4, 1024)), dim3(SP_THREADS), 0, stream,
+  hipLaunchKernelGGL(out_conv_bwd_kernel, dim3(ew_grid(npix * 4, SP_THREADS * 4, 160)), dim3(SP_THREADS), 0, stream,
                      x, (const bf16_t*)h, ldh, w, dout, (bf16_t*)dh, lddh, dw, npix);
   RIED_CHECK_LAUNCH("ried_out_conv_bwd");
   return RIED_OK;
@@ -310,38 +364,44 @@ extern "C" int ried_out_conv_bwd(const float* x, const void* h, long long ldh, c
 // spectral normalisation, one power iteration (torch/nn/utils/spectral_norm.py:97-113)
 // W: fp32 [R][K] (weight_orig viewed as a matrix).  scratch: fp32 [K + R + 2], zeroed by the first kernel's caller.
 // ---------------------------------------------------------------------------
-// t[k] = sum_r W[r][k] u[r];  n2[0] += sum t^2
-__global__ void sn_wt_u_kernel(const float* __restrict__ Wm, const float* __restrict__ u, int R, int K,
-                               float* __restrict__ t, float* __restrict__ n2) {
-  __shared__ float sh[4];
-  int k = blockIdx.x * blockDim.x + threadIdx.x;
+// t[k] = sum_r W[r][k] u[r]: 64 columns per block, the rows split over 4 waves and combined through LDS
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ Wm, const float* __restrict__ u, int R,
+                                                      int K, float* __restrict__ t) {
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
   float acc = 0.f;
   if (k < K)
-    for (int r = 0; r < R; ++r) acc += Wm[(long long)r * K + k] * u[r];
-  if (k < K) t[k] = acc;
-  float s = block_sum_256(k < K ? acc * acc : 0.f, sh);
-  if (threadIdx.x == 0) atomicAdd(n2, s);
+    for (int r = w; r < R; r += 4) acc += Wm[(long long)r * K + k] * u[r];
+  sh[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && k < K) t[k] = sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
 }
-// s[r] = sum_k W[r][k] t[k];  n2[1] += sum s^2     (one wave per row)
+// s[r] = sum_k W[r][k] t[k]     (one wave per row)
 __global__ void sn_w_v_kernel(const float* __restrict__ Wm, const float* __restrict__ t, int R, int K,
-                              float* __restrict__ s, float* __restrict__ n2) {
+                              float* __restrict__ s) {
   int lane = threadIdx.x & 63;
   int r = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (r >= R) return;
   float acc = 0.f;
   for (int k = lane; k < K; k += 64) acc += Wm[(long long)r * K + k] * t[k];
   acc = wave_sum(acc);
-  if (lane == 0) { s[r] = acc; atomicAdd(n2 + 1, acc * acc); }
+  if (lane == 0) s[r] = acc;
 }
 // power_iter = 1: v = t/|t|, Wv = s/|t|, u = Wv/|Wv|, sigma = u.Wv
-// power_iter = 0: t held v already (s = W v): sigma = u.s with the stored u
-__global__ void sn_finish_kernel(const float* __restrict__ t, const float* __restrict__ s, const float* __restrict__ n2,
-                                 int R, int K, float eps, int power_iter, float* __restrict__ u, float* __restrict__ v,
+// power_iter = 0: s = W v with the stored v: sigma = u.s with the stored u
+__global__ void sn_finish_kernel(const float* __restrict__ t, const float* __restrict__ s, int R, int K, float eps,
+                                 int power_iter, float* __restrict__ u, float* __restrict__ v,
                                  float* __restrict__ sigma) {
   __shared__ float sh[4];
   if (power_iter) {
-    float nt = fmaxf(sqrtf(n2[0]), eps);
-    float nwv = sqrtf(n2[1]) / nt;                  // |W v|
+    float a = 0.f, b = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) a += t[k] * t[k];
+    for (int r = threadIdx.x; r < R; r += blockDim.x) b += s[r] * s[r];
+    float n2t = block_sum_256(a, sh);
+    float n2s = block_sum_256(b, sh);
+    float nt = fmaxf(sqrtf(n2t), eps);
+    float nwv = sqrtf(n2s) / nt;                  // |W v|
     float nu = fmaxf(nwv, eps);
     for (int k = threadIdx.x; k < K; k += blockDim.x) v[k] = t[k] / nt;
     for (int r = threadIdx.x; r < R; r += blockDim.x) u[r] = (s[r] / nt) / nu;
@@ -359,16 +419,13 @@ extern "C" int ried_sn_sigma(const float* Wm, int R, int K, float* u, float* v, 
   RIED_CHECK_ARG(Wm && u && v && sigma && scratch && R > 0 && K > 0, "ried_sn_sigma: bad arguments");
   float* t = scratch;
   float* s = scratch + K;
-  float* n2 = scratch + K + R;
-  hipError_t e = hipMemsetAsync(n2, 0, 2 * sizeof(float), stream);
-  if (e != hipSuccess) { ried_set_error("ried_sn_sigma: memset failed"); return RIED_ERR_HIP; }
   if (power_iter) {
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, stream, Wm, u, R, K, t, n2);
-    hipLaunchKernelGGL(sn_w_v_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, stream, Wm, t, R, K, s, n2);
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3(ceil_div(K, 64)), dim3(256), 0, stream, Wm, u, R, K, t);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, stream, Wm, t, R, K, s);
   } else {
-    hipLaunchKernelGGL(sn_w_v_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, stream, Wm, v, R, K, s, n2);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(ceil_div(R, 4)), dim3(256), 0, stream, Wm, v, R, K, s);
   }
-  hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(256), 0, stream, t, s, n2, R, K, eps, power_iter, u, v, sigma);
+  hipLaunchKernelGGL(sn_finish_kernel, dim3(1), dim3(256), 0, stream, t, s, R, K, eps, power_iter, u, v, sigma);
   RIED_CHECK_LAUNCH("ried_sn_sigma");
   return RIED_OK;
 }
@@ -404,7 +461,7 @@ extern "C" int ried_sn_backward(const float* dWsn, const float* Wm, const float*
   hipError_t e = hipMemsetAsync(scratch1, 0, sizeof(float), stream);
   if (e != hipSuccess) { ried_set_error("ried_sn_backward: memset failed"); return RIED_ERR_HIP; }
   long long n = (long long)R * K;
-  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(ew_grid(n, 1024, 512)), dim3(256), 0, stream, dWsn, Wm, n, scratch1);
+  hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(ew_grid(n, 1024, 64)), dim3(256), 0, stream, dWsn, Wm, n, scratch1);
   hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3(ew_grid(n, 256, 2048)), dim3(256), 0, stream, dWsn, u, v, sigma,
                      scratch1, R, K, dW, accumulate);
   RIED_CHECK_LAUNCH("ried_sn_backward");
@@ -447,7 +504,7 @@ extern "C" int ried_mse_tap(const void* a, const void* b, long long n, float los
   RIED_CHECK_ARG(a && b && n > 0 && n % 8 == 0, "ried_mse_tap: bad arguments");
   RIED_CHECK_ARG(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)g % 16) == 0,
                  "ried_mse_tap: alignment");
-  hipLaunchKernelGGL(mse_tap_kernel, dim3(ew_grid(n / 8, SP_THREADS * 2, 1024)), dim3(SP_THREADS), 0, stream,
+  hipLaunchKernelGGL(mse_tap_kernel, dim3(ew_grid(n / 8, SP_THREADS * 2, 256)), dim3(SP_THREADS), 0, stream,
                      (const float*)a, (const float*)b, n / 8, loss_scale, loss, (bf16_t*)g, grad_scale, accumulate);
   RIED_CHECK_LAUNCH("ried_mse_tap");
   return RIED_OK;

@@ -105,6 +105,7 @@ class Ctx:
         self.sums_elems = 0           # fp32 arena zeroed at the start of every backward
         self.slab_elems = 0
         self.tmp_elems = 0
+        self.f32_elems = 0            # shared fp32 scratch (BN backward partial rows, column sums)
         self._stats_req: List[Tuple[object, str, int]] = []
         self._sums_req: List[Tuple[object, str, int]] = []
 
@@ -135,6 +136,9 @@ class Ctx:
     def need_tmp(self, n):
         self.tmp_elems = max(self.tmp_elems, n)
 
+    def need_f32(self, n):
+        self.f32_elems = max(self.f32_elems, n)
+
     def finalize(self):
         dev = self.device
         self.grad_arena = torch.zeros(max(self._grad_bytes // 2, 8), dtype=torch.bfloat16, device=dev)
@@ -152,17 +156,17 @@ class Ctx:
             setattr(owner, attr, self.sums_arena[off:off + getattr(owner, attr + "_n")])
         self.slab = torch.empty(max(self.slab_elems, 4), dtype=F32, device=dev)
         self.tmp = torch.empty(max(self.tmp_elems, 8), dtype=torch.bfloat16, device=dev)
+        self.f32 = torch.empty(max(self.f32_elems, 4), dtype=F32, device=dev)
 
     def tmp_view(self, N, H, W, C) -> View:
         assert N * H * W * C <= self.tmp.numel()
         return View(self.tmp, self.tmp.data_ptr(), C, C, N, H, W)
 
     def zero_stats(self):
-        self.stats_arena.zero_()
+        pass                     # BN partial-sum rows are fully overwritten by the conv epilogues
 
     def zero_backward(self):
         self.grad_arena.zero_()
-        self.sums_arena.zero_()
 
 
 # Deferred gradient pointers: Views handed out before Ctx.finalize() hold offsets.  Slices taken before
@@ -305,9 +309,10 @@ class ConvBN:
         self.out, self.accumulate = out, accumulate
         self.raw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
-        ctx.stats(self, "stats", 2 * cout)
+        self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, c.sh, c.sw, deconv)
+        ctx.stats(self, "stats", self.stat_rows * 2 * cout)
         if ctx.grads:
-            ctx.sums(self, "sums", 2 * cout)
+            ctx.need_f32(ops.bn_backward_scratch_floats(cout))
             ctx.need_tmp(c.N * c.Ho * c.Wo * cout)
 
     def forward(self):
@@ -315,7 +320,8 @@ class ConvBN:
         c.pack_fwd()
         if ctx.training:
             c.conv(self.raw, stats=self.stats)
-            ops.bn_finalize(self.stats, c.cout, self.raw.npix, self.save, st.b[self.bn + ".running_mean"],
+            ops.bn_finalize(self.stats, self.stat_rows, c.cout, self.raw.npix, self.save,
+                            st.b[self.bn + ".running_mean"],
                             st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"])
         else:
             c.conv(self.raw)
@@ -328,7 +334,7 @@ class ConvBN:
         ctx, c, st = self.ctx, self.core, self.ctx.st
         draw = ctx.tmp_view(c.N, c.Ho, c.Wo, c.cout)
         ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
-                        self.sums, st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True)
+                        ctx.f32, st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True)
         c.wgrad(draw, st.g[c.wname])
         if c.need_dx:
             c.pack_bwd()
@@ -346,9 +352,11 @@ class ConvBNC1:
         self.out = out
         self.raw = ops.new_view(N, self.Ho, self.Wo, cout, ctx.device)
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
-        ctx.stats(self, "stats", 2 * cout)
+        self.stat_rows = ops.conv_c1_stat_rows(N, H, W, cout, 2)
+        ctx.stats(self, "stats", self.stat_rows * 2 * cout)
         if ctx.grads:
-            ctx.sums(self, "sums", 2 * cout)
+            ctx.need_f32(ops.bn_backward_scratch_floats(cout))
+            ctx.need_f32(ops.conv_c1_wgrad_scratch_floats(cout))
             ctx.need_tmp(N * self.Ho * self.Wo * cout)
         self.x: Optional[torch.Tensor] = None
 
@@ -358,7 +366,7 @@ class ConvBNC1:
         w = st.p[self.prefix + ".conv.weight"]
         if ctx.training:
             ops.conv_c1_fwd(x, w, self.raw, 2, stats=self.stats)
-            ops.bn_finalize(self.stats, self.cout, self.raw.npix, self.save, st.b[bn + ".running_mean"],
+            ops.bn_finalize(self.stats, self.stat_rows, self.cout, self.raw.npix, self.save, st.b[bn + ".running_mean"],
                             st.b[bn + ".running_var"], st.b[bn + ".num_batches_tracked"])
         else:
             ops.conv_c1_fwd(x, w, self.raw, 2)
@@ -368,9 +376,9 @@ class ConvBNC1:
     def backward(self):
         ctx, st, bn = self.ctx, self.ctx.st, self.prefix + ".bn"
         draw = ctx.tmp_view(self.N, self.Ho, self.Wo, self.cout)
-        ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[bn + ".weight"], st.p[bn + ".bias"], self.sums,
+        ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[bn + ".weight"], st.p[bn + ".bias"], ctx.f32,
                         st.g[bn + ".weight"], st.g[bn + ".bias"], relu=True)
-        ops.conv_c1_wgrad(self.x, draw, 2, st.g[self.prefix + ".conv.weight"])   # grads were zeroed: += is =
+        ops.conv_c1_wgrad(self.x, draw, 2, st.g[self.prefix + ".conv.weight"], ctx.f32)   # grads were zeroed
 
 
 class ConvPlain:
@@ -629,12 +637,15 @@ class SNConv:
         dev = ctx.device
         self.K = cin * 9
         self.sigma = torch.ones(1, dtype=F32, device=dev)
-        self.scratch = torch.zeros(self.K + cout + 2, dtype=F32, device=dev)
+        self.scratch = torch.zeros(self.K + cout + 2, dtype=F32, device=dev)    # sn_sigma: [K + R]; sn_backward: [1]
         if not first:
             self.core = ConvCore(ctx, prefix + ".weight_orig", cin, cout, 3, stride, 1, False, xin, True)
         N, Ho, Wo, _ = out.shape
         if ctx.grads:
             ctx.need_tmp(N * Ho * Wo * cout)
+            ctx.need_f32(ops.colsum_scratch_floats(cout))
+            if first:
+                ctx.need_f32(ops.conv_c1_wgrad_scratch_floats(cout))
             self.dwsn = torch.empty(cout * self.K, dtype=F32, device=dev)
         self.x_img: Optional[torch.Tensor] = None
 
@@ -658,10 +669,10 @@ class SNConv:
         dpre = ctx.tmp_view(N, Ho, Wo, C)
         ops.ew(ops.EW_ACTBWD, out.g, dpre, y=out.v, slope=0.2)
         if wgrad:
-            ops.colsum(dpre, st.g[p + ".bias"])
+            ops.colsum(dpre, st.g[p + ".bias"], ctx.f32)
             if self.first:
                 self.dwsn.zero_()
-                ops.conv_c1_wgrad(self.x_img[n0:n1], dpre, self.stride, self.dwsn)
+                ops.conv_c1_wgrad(self.x_img[n0:n1], dpre, self.stride, self.dwsn, ctx.f32)
             else:
                 self.core.wgrad(dpre, self.dwsn, x=self.core.xin.images(n0, n1).v)
             ops.sn_backward(self.dwsn, st.p[p + ".weight_orig"], st.b[p + ".weight_u"], st.b[p + ".weight_v"],
@@ -701,6 +712,7 @@ class Attn:
             kp = N * self.n
             self.splitk = _splitk(((C + 127) // 128) * ((self.cq + 127) // 128), kp)
             ctx.need_slab(self.splitk * self.cq * C)
+            ctx.need_f32(ops.colsum_scratch_floats(self.cq))
 
     def _names(self):
         p = self.prefix
@@ -752,7 +764,7 @@ class Attn:
         ops.bgemm(q, ld, bs, 1, dS, n, n * n, 1, d, n, n, N, dk, ld, bs)
         if wgrad:
             self.db.zero_()
-            ops.colsum(qkv.g, self.db)
+            ops.colsum(qkv.g, self.db, self.ctx.f32)
             ops.conv2d_wgrad(xin.v, qkv.g, 1, 1, 1, 1, 0, 0, self.ctx.slab, self.splitk)
             ops.wgrad_reduce(self.ctx.slab, self.splitk, 1, self.cq, C, self.dw, 1, C, 1)
             for name, c0, c1 in self._names():

@@ -94,8 +94,24 @@ def pack_weight(src: torch.Tensor, dst: torch.Tensor, N, R, S, C, sn, sr, ss, sc
 
 
 # --------------------------------------------------------------------------- batch norm
-def bn_finalize(stats, C, count, save, rm=None, rv=None, nbt=None, eps=1e-5, momentum=0.1):
-    lib.ried_bn_finalize(_p(stats), C, count, eps, momentum, _p(save), _p(rm), _p(rv), _p(nbt), _stream())
+def conv2d_stat_rows(nimg, Ho, Wo, sh=1, sw=1, transposed=False) -> int:
+    return lib.ried_conv2d_stat_rows(nimg, Ho, Wo, sh, sw, int(transposed))
+
+
+def conv_c1_stat_rows(nimg, H, W, Cout, stride) -> int:
+    return lib.ried_conv_c1_stat_rows(nimg, H, W, Cout, stride)
+
+
+def bn_backward_scratch_floats(C) -> int:
+    return lib.ried_bn_backward_scratch_floats(C)
+
+
+def colsum_scratch_floats(C) -> int:
+    return lib.ried_colsum_scratch_floats(C)
+
+
+def bn_finalize(stats, nrows, C, count, save, rm=None, rv=None, nbt=None, eps=1e-5, momentum=0.1):
+    lib.ried_bn_finalize(_p(stats), nrows, C, count, eps, momentum, _p(save), _p(rm), _p(rv), _p(nbt), _stream())
 
 
 def bn_eval_stats(rm, rv, C, save, eps=1e-5):
@@ -107,10 +123,11 @@ def bn_apply(x: View, y: View, save, gamma, beta, relu=True, accumulate=False):
                       int(accumulate), _stream())
 
 
-def bn_backward(dy: View, x: View, dx: View, save, gamma, beta, sums, dgamma=None, dbeta=None, relu=True,
+def bn_backward(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma=None, dbeta=None, relu=True,
                 accumulate=False):
+    """scratch: fp32, at least bn_backward_scratch_floats(C) elements."""
     lib.ried_bn_backward(dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta),
-                         int(relu), _p(sums), _p(dgamma), _p(dbeta), int(accumulate), _stream())
+                         int(relu), _p(scratch), _p(dgamma), _p(dbeta), int(accumulate), _stream())
 
 
 # --------------------------------------------------------------------------- pooling etc.
@@ -142,8 +159,9 @@ def ew(op: int, a: View, out: View, y: Optional[View] = None, slope: float = 0.0
                 a.C, slope, _p(s), _stream())
 
 
-def colsum(a: View, out: torch.Tensor):
-    lib.ried_colsum(a.ptr, a.ld, a.npix, a.C, _p(out), _stream())
+def colsum(a: View, out: torch.Tensor, scratch: torch.Tensor):
+    """out[c] += sum over pixels; scratch: fp32, at least colsum_scratch_floats(C) elements."""
+    lib.ried_colsum(a.ptr, a.ld, a.npix, a.C, _p(out), _p(scratch), _stream())
 
 
 def dot(a: View, b: Optional[View], scale: float, out: torch.Tensor):
@@ -188,9 +206,16 @@ def conv_c1_fwd(x: torch.Tensor, w, y: View, stride, sigma=None, bias=None, in_s
                          act, _p(stats), _stream())
 
 
-def conv_c1_wgrad(x: torch.Tensor, dy: View, stride, dw: torch.Tensor, in_scale=1.0, in_shift=0.0):
+def conv_c1_wgrad_scratch_floats(Cout) -> int:
+    return lib.ried_conv_c1_wgrad_scratch_floats(Cout)
+
+
+def conv_c1_wgrad(x: torch.Tensor, dy: View, stride, dw: torch.Tensor, scratch: torch.Tensor, in_scale=1.0,
+                  in_shift=0.0):
+    """dw += weight gradient; scratch: fp32, at least conv_c1_wgrad_scratch_floats(Cout) elements."""
     n, h, wd = x.shape[0], x.shape[-2], x.shape[-1]
-    lib.ried_conv_c1_wgrad(_p(x), dy.ptr, dy.ld, n, h, wd, dy.C, stride, in_scale, in_shift, _p(dw), _stream())
+    lib.ried_conv_c1_wgrad(_p(x), dy.ptr, dy.ld, n, h, wd, dy.C, stride, in_scale, in_shift, _p(dw), _p(scratch),
+                           _stream())
 
 
 def conv_c1_dgrad(dy: View, w, dx: torch.Tensor, sigma=None, scale=1.0, accumulate=False):

@@ -1,7 +1,7 @@
 """Block-level parity on the GPU: every block of src/rinet.py as a HIP plan, forward and backward, against the
 golden vectors made from the reference (fp32) and against the bf16-storage-emulating oracle.
 
-Tolerances: output and input gradient vs emulation: mean |err| <= 2e-2 * mean|ref|, max <= 1e-1 * max|ref|;
+Tolerances: output and input gradient vs emulation: mean |err| <= 3e-2 * mean|ref|, max <= 1e-1 * max|ref|;
 vs the fp32 golden: output mean |err| <= 5e-2 * mean|ref|, input gradient cosine >= 0.97; parameter gradients vs
 emulation: cosine >= 0.985, norm within 6 %.
 """
@@ -68,7 +68,7 @@ class _Stripped(O.Params):
         super().set(name.lstrip("."), value)
 
 
-def _close(got, ref, what, mx=1e-1, mean=2e-2):
+def _close(got, ref, what, mx=1e-1, mean=3e-2):
     e = (got.double() - ref.double()).abs()
     assert e.max().item() <= mx * ref.abs().max().item(), f"{what}: max err {e.max().item():.4g} vs {ref.abs().max().item():.4g}"
     assert e.mean().item() <= mean * ref.abs().mean().item(), f"{what}: mean err {e.mean().item():.4g} vs {ref.abs().mean().item():.4g}"

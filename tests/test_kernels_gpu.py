@@ -70,11 +70,17 @@ def test_conv2d_forward_stats(cin, cout, k, s, p, H):
     xv = to_view(x)
     Ho, Wo = ref.shape[-2:]
     yv = ops.new_view(3, Ho, Wo, cout)
-    stats = torch.zeros(2, cout, device=DEV)
+    rows = ops.conv2d_stat_rows(3, Ho, Wo)
+    stats = torch.full((rows, 2, cout), float("nan"), device=DEV)        # every row must be overwritten
     ops.conv2d(xv, pack(w), yv, k[0], k[1], s, s, p[0], p[1], stats=stats)
     close(from_view(yv), ref, what="y")
-    close(stats[0].cpu(), ref.sum((0, 2, 3)), 3e-3 * 10, "sum")
-    close(stats[1].cpu(), (ref * ref).sum((0, 2, 3)), 3e-3, "sumsq")
+    st = stats.sum(0)
+    close(st[0].cpu(), ref.sum((0, 2, 3)), 3e-3 * 10, "sum")
+    close(st[1].cpu(), (ref * ref).sum((0, 2, 3)), 3e-3, "sumsq")
+    save = torch.empty(2, cout, device=DEV)
+    ops.bn_finalize(stats, rows, cout, ref.numel() // cout, save)
+    close(save[0].cpu(), ref.mean((0, 2, 3)), 3e-3 * 10, "mean")
+    close(save[1].cpu(), torch.rsqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5), 3e-3, "invstd")
 
 
 def test_conv2d_bias_act_slice_accumulate():
@@ -110,8 +116,11 @@ def test_conv2d_transposed(cin, cout, k, s, p, H, op):
     Ho, Wo = ref.shape[-2:]
     yv = ops.new_view(2, Ho, Wo, cout)
     wp = pack(w.permute(1, 0, 2, 3))                                      # -> [Cout][kh][kw][Cin]
-    ops.conv2d(to_view(x), wp, yv, k[0], k[1], s, s, p[0], p[1], transposed=True)
+    rows = ops.conv2d_stat_rows(2, Ho, Wo, s, s, True)
+    stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
+    ops.conv2d(to_view(x), wp, yv, k[0], k[1], s, s, p[0], p[1], transposed=True, stats=stats)
     close(from_view(yv), ref, what="y")
+    close(stats.sum(0)[1].cpu(), (ref * ref).sum((0, 2, 3)), 3e-3, "sumsq over phases")
 
 
 WGRAD_CASES = [
@@ -197,7 +206,7 @@ def test_bn_forward_backward():
     save = torch.empty(2, C, device=DEV)
     rm_d, rv_d = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
     nbt = torch.zeros((), dtype=torch.long, device=DEV)
-    ops.bn_finalize(stats, C, N * H * H, save, rm_d, rv_d, nbt)
+    ops.bn_finalize(stats, 1, C, N * H * H, save, rm_d, rv_d, nbt)
     yv = ops.new_view(N, H, H, C)
     ops.bn_apply(xv, yv, save, gamma.to(DEV), beta.to(DEV))
     close(from_view(yv), y.detach(), what="y")
@@ -205,9 +214,9 @@ def test_bn_forward_backward():
     close(rv_d.cpu(), rv, 1e-4, "running_var")
     assert nbt.item() == 1
     dxv = ops.new_view(N, H, H, C)
-    sums = torch.zeros(2, C, device=DEV)
+    scratch = torch.full((ops.bn_backward_scratch_floats(C),), float("nan"), device=DEV)
     dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
-    ops.bn_backward(to_view(dy), xv, dxv, save, gamma.to(DEV), beta.to(DEV), sums, dg, db)
+    ops.bn_backward(to_view(dy), xv, dxv, save, gamma.to(DEV), beta.to(DEV), scratch, dg, db)
     close(from_view(dxv), xr.grad, what="dx")
     close(dg.cpu(), g2.grad, 5e-3, "dgamma")
     close(db.cpu(), b2.grad, 5e-3, "dbeta")
@@ -302,17 +311,19 @@ def test_conv_c1(cout, stride):
     y = F.leaky_relu(F.conv2d(xa, w / sigma, b, stride, 1), 0.2)
     Ho = y.shape[-1]
     yv = ops.new_view(N, Ho, Ho, cout)
-    stats = torch.zeros(2, cout, device=DEV)
+    rows = ops.conv_c1_stat_rows(N, H, H, cout, stride)
+    stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
     ops.conv_c1_fwd(x.to(DEV), w.detach().to(DEV), yv, stride, sigma=sigma.to(DEV), bias=b.to(DEV),
                     in_scale=1 / 4096.0, in_shift=0.25, act=2, stats=stats)
     close(from_view(yv), y.detach(), what="y")
     raw = F.conv2d(xa, w.detach() / sigma, None, stride, 1)
-    close(stats[0].cpu(), raw.sum((0, 2, 3)), 1e-3, "sum")
+    close(stats.sum(0)[0].cpu(), raw.sum((0, 2, 3)), 1e-3, "sum")
     dy = r(*y.shape, seed=26)
     raw2 = F.conv2d(xa, w, None, stride, 1)
     (gw,) = torch.autograd.grad(raw2, w, dy)
     dw = torch.zeros(cout, 9, device=DEV)
-    ops.conv_c1_wgrad(x.to(DEV), to_view(dy), stride, dw, in_scale=1 / 4096.0, in_shift=0.25)
+    scr = torch.full((ops.conv_c1_wgrad_scratch_floats(cout),), float("nan"), device=DEV)
+    ops.conv_c1_wgrad(x.to(DEV), to_view(dy), stride, dw, scr, in_scale=1 / 4096.0, in_shift=0.25)
     close(dw.cpu().reshape(cout, 1, 3, 3), gw, 3e-3, "dw")
     if stride == 1:
         xr = xa.clone().requires_grad_(True)
@@ -356,7 +367,7 @@ def test_spectral_norm_sigma_and_backward():
     Wsn.backward(dWsn)
     ud, vd = u.to(DEV), v.to(DEV)
     sg = torch.zeros(1, device=DEV)
-    scratch = torch.zeros(K + R + 2, device=DEV)
+    scratch = torch.full((K + R,), float("nan"), device=DEV)
     ops.sn_sigma(Wm.to(DEV), R, K, ud, vd, sg, scratch, True)
     close(ud.cpu(), u1, 1e-5, "u")
     close(vd.cpu(), v1, 1e-5, "v")
@@ -400,7 +411,7 @@ def test_misc_elementwise():
     ops.ew(ops.EW_AXPY, av, o, y=yv, s=s)
     close(from_view(o), 0.7 * a + y, what="axpy")
     cs = torch.zeros(C, device=DEV)
-    ops.colsum(av, cs)
+    ops.colsum(av, cs, torch.empty(ops.colsum_scratch_floats(C), device=DEV))
     close(cs.cpu(), a.sum((0, 2, 3)), 1e-3, "colsum")
     d = torch.zeros(1, device=DEV)
     ops.dot(av, yv, 0.5, d)
