@@ -44,7 +44,10 @@ int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long 
                 const float* bias, int act, float* stats, int accumulate, int out_f32, float* y2, long long ldy2,
                 ried_stream_t stream);
 
-int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int sh, int sw, int transposed);
+int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int Cout, int sh, int sw, int transposed);
+/* tuning hook, no counterpart in the reference: force the (Cout tile, pixel tile, LDS stages) of later ried_conv2d
+ * calls; bm = 0 restores the built-in choice */
+int ried_conv2d_force_tile(int bm, int bn, int nst);
 
 /* Weight-gradient partial sums (autograd of the convs above).  g is the tensor seen through the kernel window
  * (Conv2d: the layer input; ConvTranspose2d: the output gradient), p the tensor indexed by output pixel.

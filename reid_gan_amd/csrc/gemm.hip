@@ -60,6 +60,7 @@ struct GemmParams {
   int taps;       // conv: kh*kw; otherwise 1 (transposed: computed per phase)
   int splitk;
   int tiles_m;
+  unsigned A_bytes, B_bytes;   // extent of the operands in bytes (buffer descriptors of the LDS-DMA kernel)
 };
 
 constexpr int BK = 32;
@@ -251,6 +252,126 @@ __device__ __forceinline__ bf16x8_t read_frag(const bf16_t* lds, int rowbase, in
   }
 }
 
+// ---------------------------------------------------------------------------
+// epilogue shared by the GEMM kernels: acc[i][j] is the 16x16 tile (i along m, j along n) of wave (wm, wn)
+// ---------------------------------------------------------------------------
+template <int BM, int BN, bool WGRAD>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0,
+                                              int tn, int pa, int pb, long long batch, int ntiles_n, void* smem) {
+  constexpr int TM = BM / 32, TN = BN / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const GemmEpilogue& E = P.E;
+  const float gam = E.gamma ? E.gamma[0] : 0.f;
+  char* outb = (char*)E.out;
+  long long obase = batch * E.batch_stride + (long long)blockIdx.y * E.tap_stride;
+  if constexpr (WGRAD) obase += (long long)blockIdx.z * E.batch_stride;
+  float ssum[TM][4], ssq[TM][4];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { ssum[i][q] = 0.f; ssq[i][q] = 0.f; }
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
+    bool nok = n < P.N;
+    long long orow = n;
+    if (E.phase_mode) {          // logical (img, hq, wq) of this phase -> physical pixel
+      int hw = E.Hq * E.Wq;
+      int img = n / hw, rem = n - img * hw;
+      int hq = rem / E.Wq, wq = rem - hq * E.Wq;
+      orow = (long long)img * E.HoWo_full + (long long)(hq * E.sh + pa) * E.Wo_full + (wq * E.sw + pb);
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] * E.alpha;
+      if (E.stats) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ssum[i][q] += v[q]; ssq[i][q] += v[q] * v[q]; }
+      }
+      if (!(nok && m < P.M)) continue;
+      if (E.bias) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += E.bias[m + q];
+      }
+      if (E.act == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+      } else if (E.act == 2) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.2f * v[q];
+      }
+      if (E.gamma) {
+        const bf16_t* rp = E.resid + batch * E.resid_batch_stride + orow * E.ld_resid + m;
+        u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
+        v[0] = gam * v[0] + bflo(rr[0]); v[1] = gam * v[1] + bfhi(rr[0]);
+        v[2] = gam * v[2] + bflo(rr[1]); v[3] = gam * v[3] + bfhi(rr[1]);
+      }
+      if (E.out2) *reinterpret_cast<f32x4*>(E.out2 + orow * E.ldc2 + m) = f32x4{v[0], v[1], v[2], v[3]};
+      long long off = obase + orow * E.ldc + m;
+      if (E.out_f32) {
+        float* op = (float*)outb + off;
+        if (E.accumulate) {
+          f32x4 o = *reinterpret_cast<f32x4*>(op);
+          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+        }
+        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
+      } else {
+        bf16_t* op = (bf16_t*)outb + off;
+        if (E.accumulate) {
+          u32x2 o = *reinterpret_cast<u32x2*>(op);
+          v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
+        }
+        *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+      }
+    }
+  }
+  if (E.stats) {
+    // Per-block partial sums, one row of [2][M] per (phase, pixel tile): same-address float atomics serialise at
+    // about 0.1 us each on this part, which at thousands of blocks would dwarf the convolution itself.
+    // Rows n that are out of range were loaded as zeros, so they add nothing.
+    float* red = reinterpret_cast<float*>(smem);          // [2][BM]; the k loop ended with a barrier
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a = ssum[i][q], b = ssq[i][q];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        ssum[i][q] = a; ssq[i][q] = b;
+      }
+    }
+    if (wn == 1 && (lane & 15) == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int ml = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
+          red[ml] = ssum[i][q]; red[BM + ml] = ssq[i][q];
+        }
+    }
+    __syncthreads();
+    if (wn == 0 && (lane & 15) == 0) {
+      float* row = E.stats + ((long long)blockIdx.y * ntiles_n + tn) * 2 * P.M;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int ml = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
+          int m = m0 + ml;
+          if (m < P.M) {
+            row[m] = ssum[i][q] + red[ml];
+            row[P.M + m] = ssq[i][q] + red[BM + ml];
+          }
+        }
+    }
+  }
+}
+
 template <int BM, int BN, int AKIND, int BKIND>
 __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
   using GA = TileGeom<BM>;
@@ -364,123 +485,200 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
     __syncthreads();
   }
 
-  // ------------------------------------------------------------------ epilogue
-  const GemmEpilogue& E = P.E;
-  const float gam = E.gamma ? E.gamma[0] : 0.f;
-  char* outb = (char*)E.out;
-  long long obase = batch * E.batch_stride + (long long)blockIdx.y * E.tap_stride;
-  if constexpr (WGRAD) obase += (long long)blockIdx.z * E.batch_stride;
-  float ssum[TM][4], ssq[TM][4];
+  gemm_epilogue<BM, BN, WGRAD>(P, acc, m0, n0, tn, pa, pb, batch, gridDim.x / P.tiles_m, smem);
+}
+
+// ---------------------------------------------------------------------------
+// Convolution forward / data gradient, second form: both operands go HBM -> LDS by LDS-DMA
+// (global_load_lds, 16 bytes per lane) into a ring of NST stage buffers, BK = 64 per stage, with the
+// loads of NST-1 stages in flight across the per-step barrier (counted vmcnt, raw s_barrier).
+//
+// K is the flattened (tap, channel) axis in 16-byte chunks, so a stage may straddle taps and layers
+// with few input channels do not pad every tap up to the stage depth.  A lane owns one chunk column
+// (kq) and NLA + NLB rows; padding pixels, rows past the edge of the problem and chunks past the end
+// of K use a buffer offset beyond the descriptor's range, for which the DMA writes zeros: no branches.
+//
+// LDS image of an operand stage: [rows][8 chunks] with 128-byte rows, chunk q of row r stored in slot
+// q ^ (r & 7).  The DMA destination is lane-linear (wave base + 16 * lane), so the swizzle is applied
+// to the SOURCE chunk a lane fetches and again when the fragments are read (ds_read_b128,
+// conflict-free per 16-lane group).
+// ---------------------------------------------------------------------------
+#define GLDS_OOB 0xFFFFFFF0u     // a byte offset no operand reaches (host-checked): the DMA then writes zeros
+
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                           (int)byte_off, 0, 0, 0);
+}
+
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
+  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int NLA = BM / 32, NLB = BN / 32;         // 16-byte DMA loads per lane per stage
+  constexpr int STAGE = (BM + BN) * 128;              // bytes per stage: A image then B image
+  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // XCD-aware order: consecutive hardware block ids go round-robin over the 8 XCDs; give each XCD a
+  // contiguous run of logical tiles so that the blocks sharing a pixel tile hit one L2.
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid % P.tiles_m, tn = bid / P.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const GemmOperand& X = P.B;
+  int pa = 0, pb = 0, r0 = 0, s0 = 0, ti_n = X.kh, tj_n = X.kw;
+  const int dir = X.transposed ? -1 : 1;
+  if (X.transposed) {                     // blockIdx.y = output phase; only its non-zero taps
+    pa = blockIdx.y / X.sw; pb = blockIdx.y % X.sw;
+    r0 = (pa + X.ph) % X.sh; s0 = (pb + X.pw) % X.sw;
+    ti_n = (X.kh - r0 + X.sh - 1) / X.sh; tj_n = (X.kw - s0 + X.sw - 1) / X.sw;
+  }
+  const int rstep = X.transposed ? X.sh : 1, sstep = X.transposed ? X.sw : 1;
+  const int CPT = P.K >> 3;                             // chunks per tap
+  const int nsteps = (ti_n * tj_n * CPT + 7) >> 3;
+
+  // this lane's rows and chunk column
+  const int rowp = tid >> 3;
+  const int kq = (tid & 7) ^ (rowp & 7);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A.p, 0, P.A_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B.p, 0, P.B_bytes, 0x00020000);
+  unsigned wrow[NLA];                                   // byte offset of the row in the packed weights
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) {
+    int m = m0 + i * 32 + rowp;
+    wrow[i] = m < P.M ? (unsigned)m * (unsigned)P.A.ld * 2u : GLDS_OOB;      // stays out of range after + wk: wk < 2^28
+  }
+  int gy[NLB], gx[NLB], pix[NLB];
+#pragma unroll
+  for (int i = 0; i < NLB; ++i) {
+    int n = n0 + i * 32 + rowp;
+    int hw = X.Ho * X.Wo;
+    int img = n / hw, rem = n - img * hw;
+    int oy = rem / X.Wo, ox = rem - oy * X.Wo;
+    if (X.transposed) { gy[i] = oy + (pa + X.ph - r0) / X.sh; gx[i] = ox + (pb + X.pw - s0) / X.sw; }
+    else              { gy[i] = oy * X.sh - X.ph;             gx[i] = ox * X.sw - X.pw; }
+    pix[i] = (img * X.H + gy[i]) * X.W + gx[i];
+    if (n >= P.N) gy[i] = -(1 << 24);                   // never inside the image
+  }
+  int c, ti, tj;
+  { int tap = kq / CPT; c = kq - tap * CPT; ti = tap / tj_n; tj = tap - ti * tj_n; }
+
+  char* const lds_wave = smem + wave * 1024;            // + i * 4096 per row pass, + BM * 128 for B
+  const unsigned ldx2 = (unsigned)X.ld * 2u;
+
+  // Offsets are 16-byte aligned, so OR-ing GLDS_OOB into one leaves it out of range whatever its value: validity
+  // is carried as a mask (0 or GLDS_OOB) and never as a branch around a load, which keeps the number of DMA
+  // instructions per stage exact for the counted waits below.
+  auto issue = [&](int buf) {
+    char* dst = lds_wave + buf * STAGE;
+    unsigned inval = ti < ti_n ? 0u : GLDS_OOB;
+    asm volatile("" : "+v"(inval));
+    const unsigned wk = (unsigned)(((r0 + ti * rstep) * X.kw + (s0 + tj * sstep)) * P.K + c * 8) * 2u;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) glds16(rsA, (wrow[i] + wk) | inval, dst + i * 4096);
+    const int dpx = dir * (ti * X.W + tj);
+    const unsigned cb = (unsigned)c * 16u;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      int hi = gy[i] + dir * ti, wi = gx[i] + dir * tj;
+      unsigned bad = ((unsigned)hi < (unsigned)X.H && (unsigned)wi < (unsigned)X.W) ? 0u : GLDS_OOB;
+      glds16(rsB, ((unsigned)(pix[i] + dpx) * ldx2 + cb) | bad | inval, dst + BM * 128 + i * 4096);
+    }
+    c += 8;
+    while (c >= CPT) {
+      c -= CPT;
+      if (++tj == tj_n) { tj = 0; ++ti; }
+    }
+  };
+
+  f32x4 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { ssum[i][q] = 0.f; ssq[i][q] = 0.f; }
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const int frow = (lane & 15) * 128;
+  const int sw0 = (((lane >> 4)) ^ (lane & 7)) << 4, sw1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
+  auto compute = [&](int buf) {
+    const char* sa = smem + buf * STAGE + wm * (BM / 2) * 128 + frow;
+    const char* sb = smem + buf * STAGE + BM * 128 + wn * (BN / 2) * 128 + frow;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
-    bool nok = n < P.N;
-    long long orow = n;
-    if (E.phase_mode) {          // logical (img, hq, wq) of this phase -> physical pixel
-      int hw = E.Hq * E.Wq;
-      int img = n / hw, rem = n - img * hw;
-      int hq = rem / E.Wq, wq = rem - hq * E.Wq;
-      orow = (long long)img * E.HoWo_full + (long long)(hq * E.sh + pa) * E.Wo_full + (wq * E.sw + pb);
-    }
+    for (int ks = 0; ks < 2; ++ks) {
+      const int sw = ks ? sw1 : sw0;
+      bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
-      float v[4];
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + sw);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] * E.alpha;
-      if (E.stats) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { ssum[i][q] += v[q]; ssq[i][q] += v[q] * v[q]; }
-      }
-      if (!(nok && m < P.M)) continue;
-      if (E.bias) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += E.bias[m + q];
-      }
-      if (E.act == 1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-      } else if (E.act == 2) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.2f * v[q];
-      }
-      if (E.gamma) {
-        const bf16_t* rp = E.resid + batch * E.resid_batch_stride + orow * E.ld_resid + m;
-        u32x2 rr = *reinterpret_cast<const u32x2*>(rp);
-        v[0] = gam * v[0] + bflo(rr[0]); v[1] = gam * v[1] + bfhi(rr[0]);
-        v[2] = gam * v[2] + bflo(rr[1]); v[3] = gam * v[3] + bfhi(rr[1]);
-      }
-      if (E.out2) *reinterpret_cast<f32x4*>(E.out2 + orow * E.ldc2 + m) = f32x4{v[0], v[1], v[2], v[3]};
-      long long off = obase + orow * E.ldc + m;
-      if (E.out_f32) {
-        float* op = (float*)outb + off;
-        if (E.accumulate) {
-          f32x4 o = *reinterpret_cast<f32x4*>(op);
-          v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-        }
-        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-      } else {
-        bf16_t* op = (bf16_t*)outb + off;
-        if (E.accumulate) {
-          u32x2 o = *reinterpret_cast<u32x2*>(op);
-          v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
-        }
-        *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
-      }
-    }
-  }
-  if (E.stats) {
-    // Per-block partial sums, one row of [2][M] per (phase, pixel tile): same-address float atomics serialise at
-    // about 0.1 us each on this part, which at thousands of blocks would dwarf the convolution itself.
-    // Rows n that are out of range were loaded as zeros, so they add nothing.
-    float* red = reinterpret_cast<float*>(smem);          // [2][BM]; the k loop ended with a barrier
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float a = ssum[i][q], b = ssq[i][q];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        ssum[i][q] = a; ssq[i][q] = b;
-      }
-    }
-    if (wn == 1 && (lane & 15) == 0) {
+      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 2048 + sw);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int ml = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
-          red[ml] = ssum[i][q]; red[BM + ml] = ssq[i][q];
-        }
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
-    if (wn == 0 && (lane & 15) == 0) {
-      float* row = E.stats + ((long long)blockIdx.y * gridDim.x / P.tiles_m + tn) * 2 * P.M;
+  };
+
+  // prologue: NST-1 stages in flight (stages past the end of K fetch zeros: uniform counts)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          int ml = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
-          int m = m0 + ml;
-          if (m < P.M) {
-            row[m] = ssum[i][q] + red[ml];
-            row[P.M + m] = ssq[i][q] + red[BM + ml];
-          }
-        }
-    }
+  for (int s = 0; s < NST - 1; ++s) issue(s);
+  int rd = 0, wr = NST - 1;
+  for (int step = 0; step < nsteps; ++step) {
+    // the DMA of stage `step` has landed for this wave's loads once at most NST-2 later stages are outstanding;
+    // the barrier extends that to every wave's loads and retires all reads of the buffer refilled next
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NLA + NLB)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(wr);
+    compute(rd);
+    rd = rd + 1 == NST ? 0 : rd + 1;
+    wr = wr + 1 == NST ? 0 : wr + 1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may outlive the block or race the epilogue
+  __builtin_amdgcn_s_barrier();
+  gemm_epilogue<BM, BN, false>(P, acc, m0, n0, tn, pa, pb, 0, gridDim.x / P.tiles_m, smem);
+}
+
+// Tile of the convolution kernel for a problem: Cout x pixels per phase.  Small problems take 64-pixel tiles
+// (more blocks than CUs matter more than MFMA efficiency there).
+struct ConvTile { int bm, bn, nst; };
+static int g_forced_tile[3] = {0, 0, 0};
+// Tuning hook: force the tile (bm, bn, nst) of every later ried_conv2d call in this process; bm = 0 restores the
+// built-in choice.  Layers with Cout <= 64 keep bm = 64.
+extern "C" int ried_conv2d_force_tile(int bm, int bn, int nst) {
+  g_forced_tile[0] = bm; g_forced_tile[1] = bn; g_forced_tile[2] = nst;
+  return RIED_OK;
+}
+static ConvTile choose_conv_tile(int Cout, long long npix, int phases) {
+  const int* forced = g_forced_tile;
+  ConvTile t;
+  // Measured on MI355X over the layers of the training step: two LDS stages always beat three or four (blocks per
+  // CU are worth more than DMA depth), and the 64-pixel tile wins whenever the 128-pixel grid would leave CUs
+  // idle or end in a mostly empty last round.  Model: time ~ rounds over the resident-block slots x tile cost.
+  t.bm = Cout <= 64 ? 64 : 128;
+  t.nst = 2;
+  const long long tiles_m = ceil_div(Cout, t.bm);
+  const long long b128 = tiles_m * ceil_div(npix, 128) * phases, b64 = tiles_m * ceil_div(npix, 64) * phases;
+  const int cus = 256;
+  const int slots128 = cus * (t.bm == 128 ? 2 : 3), slots64 = cus * (t.bm == 128 ? 3 : 5);
+  const double cost128 = (double)ceil_div(b128, slots128) * 1.0, cost64 = (double)ceil_div(b64, slots64) * 0.62;
+  t.bn = cost128 <= cost64 ? 128 : 64;
+  if (forced[0] > 0) {
+    t.bm = Cout <= 64 ? 64 : forced[0]; t.bn = forced[1]; t.nst = forced[2];
+  }
+  return t;
 }
 
 // rows of the partial-statistics buffer a ried_conv2d call with stats writes: [rows][2][Cout]
-extern "C" int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int sh, int sw, int transposed) {
+extern "C" int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int Cout, int sh, int sw, int transposed) {
   long long npix = transposed ? (long long)nimg * (Ho / sh) * (Wo / sw) : (long long)nimg * Ho * Wo;
   int phases = transposed ? sh * sw : 1;
-  return phases * ceil_div(npix, 128);
+  ConvTile t = choose_conv_tile(Cout, npix, phases);
+  return phases * ceil_div(npix, t.bn);
 }
 
 // ---------------------------------------------------------------------------
@@ -543,15 +741,25 @@ extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y,
   P.E.accumulate = accumulate;
   RIED_CHECK_ARG(!y2 || (ldy2 % 4 == 0 && ldy2 >= Cout && ((uintptr_t)y2 % 16) == 0), "ried_conv2d: bad y2 view");
   P.E.out2 = y2; P.E.ldc2 = ldy2;
-  if (Cout <= 64) {
-    P.tiles_m = ceil_div(Cout, 64);
-    dim3 grid(P.tiles_m * ceil_div(npix, 128), phases, 1);
-    launch<64, 128, OP_PLAIN_K, OP_GATHER_K>(P, grid, stream);
-  } else {
-    P.tiles_m = ceil_div(Cout, 128);
-    dim3 grid(P.tiles_m * ceil_div(npix, 128), phases, 1);
-    launch<128, 128, OP_PLAIN_K, OP_GATHER_K>(P, grid, stream);
+  long long a_bytes = (long long)Cout * kh * kw * Cin * 2;
+  long long b_bytes = (((long long)nimg * H * W - 1) * ldx + Cin) * 2;
+  RIED_CHECK_ARG(a_bytes < (long long)GLDS_OOB - (1 << 28) && b_bytes < (long long)GLDS_OOB,
+                 "ried_conv2d: operand larger than 4 GiB");
+  P.A_bytes = (unsigned)a_bytes; P.B_bytes = (unsigned)b_bytes;
+  ConvTile t = choose_conv_tile(Cout, npix, phases);
+  P.tiles_m = ceil_div(Cout, t.bm);
+  dim3 grid(P.tiles_m * ceil_div(npix, t.bn), phases, 1);
+#define RIED_CONV_CASE(BM_, BN_, NST_)                                                                  \
+  if (t.bm == BM_ && t.bn == BN_ && t.nst == NST_) {                                                    \
+    hipLaunchKernelGGL((conv_glds_kernel<BM_, BN_, NST_>), grid, dim3(256), 0, stream, P);              \
+    launched = true;                                                                                    \
   }
+  bool launched = false;
+  RIED_CONV_CASE(128, 128, 2) RIED_CONV_CASE(128, 128, 3) RIED_CONV_CASE(128, 64, 2) RIED_CONV_CASE(128, 64, 3)
+  RIED_CONV_CASE(128, 64, 4) RIED_CONV_CASE(64, 128, 2) RIED_CONV_CASE(64, 128, 3) RIED_CONV_CASE(64, 128, 4)
+  RIED_CONV_CASE(64, 64, 2) RIED_CONV_CASE(64, 64, 3) RIED_CONV_CASE(64, 64, 4)
+#undef RIED_CONV_CASE
+  RIED_CHECK_ARG(launched, "ried_conv2d: no kernel for tile %dx%dx%d", t.bm, t.bn, t.nst);
   RIED_CHECK_LAUNCH("ried_conv2d");
   return RIED_OK;
 }

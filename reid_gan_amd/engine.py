@@ -309,7 +309,7 @@ class ConvBN:
         self.out, self.accumulate = out, accumulate
         self.raw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
-        self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, c.sh, c.sw, deconv)
+        self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, c.cout, c.sh, c.sw, deconv)
         ctx.stats(self, "stats", self.stat_rows * 2 * cout)
         if ctx.grads:
             ctx.need_f32(ops.bn_backward_scratch_floats(cout))

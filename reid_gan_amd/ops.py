@@ -94,8 +94,8 @@ def pack_weight(src: torch.Tensor, dst: torch.Tensor, N, R, S, C, sn, sr, ss, sc
 
 
 # --------------------------------------------------------------------------- batch norm
-def conv2d_stat_rows(nimg, Ho, Wo, sh=1, sw=1, transposed=False) -> int:
-    return lib.ried_conv2d_stat_rows(nimg, Ho, Wo, sh, sw, int(transposed))
+def conv2d_stat_rows(nimg, Ho, Wo, Cout, sh=1, sw=1, transposed=False) -> int:
+    return lib.ried_conv2d_stat_rows(nimg, Ho, Wo, Cout, sh, sw, int(transposed))
 
 
 def conv_c1_stat_rows(nimg, H, W, Cout, stride) -> int:

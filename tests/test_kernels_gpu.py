@@ -70,7 +70,7 @@ def test_conv2d_forward_stats(cin, cout, k, s, p, H):
     xv = to_view(x)
     Ho, Wo = ref.shape[-2:]
     yv = ops.new_view(3, Ho, Wo, cout)
-    rows = ops.conv2d_stat_rows(3, Ho, Wo)
+    rows = ops.conv2d_stat_rows(3, Ho, Wo, cout)
     stats = torch.full((rows, 2, cout), float("nan"), device=DEV)        # every row must be overwritten
     ops.conv2d(xv, pack(w), yv, k[0], k[1], s, s, p[0], p[1], stats=stats)
     close(from_view(yv), ref, what="y")
@@ -116,7 +116,7 @@ def test_conv2d_transposed(cin, cout, k, s, p, H, op):
     Ho, Wo = ref.shape[-2:]
     yv = ops.new_view(2, Ho, Wo, cout)
     wp = pack(w.permute(1, 0, 2, 3))                                      # -> [Cout][kh][kw][Cin]
-    rows = ops.conv2d_stat_rows(2, Ho, Wo, s, s, True)
+    rows = ops.conv2d_stat_rows(2, Ho, Wo, cout, s, s, True)
     stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
     ops.conv2d(to_view(x), wp, yv, k[0], k[1], s, s, p[0], p[1], transposed=True, stats=stats)
     close(from_view(yv), ref, what="y")
