@@ -59,6 +59,15 @@ int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg, int H, int
  * fp32 master gradient. */
 int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp, int Cg, float* out, long long st, long long sp,
                       long long sg, float scale, int accumulate, ried_stream_t stream);
+/* Job-table forms (one launch for all layers of a network; the reference has one torch op per layer).  A job is a
+ * row of 64-bit words holding pointers and integers; blockmap[b] = (job, chunk): block b handles elements
+ * [2048*chunk, 2048*(chunk+1)) of its job.
+ *   pack job (13 words): src, dst, sigma|0, N, R, S, C, sn, sr, ss, sc, dst_pitch, dst_f32 - as ried_pack_weight,
+ *     with dst[n*dst_pitch + (r*S+s)*C + c]; dst is fp32 instead of bf16 when dst_f32 != 0.
+ *   reduce job (11 words): slab, out, splitk, split_stride, taps, Cp, Cg, st, sp, sg, accumulate - as
+ *     ried_wgrad_reduce with scale 1 and slab[k*split_stride + (tap*Cp + p)*Cg + g]. */
+int ried_pack_jobs(const long long* jobs, const int* blockmap, int nblocks, ried_stream_t stream);
+int ried_wgrad_reduce_jobs(const long long* jobs, const int* blockmap, int nblocks, ried_stream_t stream);
 
 /* Batched out[b][n][m] = alpha * sum_k A[b][m][k] * B[b][n][k]; a_tr / b_tr: operand stored [k][row].
  * Replaces torch.bmm at src/rinet.py:173,177 and their autograd.  gamma/resid: out = gamma[0]*value + resid. */

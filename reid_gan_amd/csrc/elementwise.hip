@@ -91,6 +91,81 @@ extern "C" int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp
 }
 
 // ---------------------------------------------------------------------------
+// Job-table forms: one launch packs every weight of a network / reduces every weight-gradient slab of a
+// backward pass.  A job is a row of 64-bit words (pointers and integers alike); blockmap[b] = (job, chunk):
+// block b handles elements [chunk * JOB_CHUNK, (chunk + 1) * JOB_CHUNK) of its job.
+// ---------------------------------------------------------------------------
+#define JOB_CHUNK 2048
+#define PACK_JOB_WORDS 13
+// pack job: src, dst, sigma, N, R, S, C, sn, sr, ss, sc, dst_pitch, dst_f32
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const long long* __restrict__ jobs,
+                                                        const int* __restrict__ blockmap) {
+  const long long* J = jobs + (long long)blockmap[2 * blockIdx.x] * PACK_JOB_WORDS;
+  const float* src = (const float*)J[0];
+  const float* sigma = (const float*)J[2];
+  const int R = (int)J[4], S = (int)J[5], C = (int)J[6];
+  const long long sn = J[7], sr = J[8], ss = J[9], sc = J[10], pitch = J[11];
+  const long long inner = (long long)R * S * C, total = J[3] * inner;
+  const float inv = sigma ? 1.f / sigma[0] : 1.f;
+  long long i0 = (long long)blockmap[2 * blockIdx.x + 1] * JOB_CHUNK;
+#pragma unroll
+  for (int u = 0; u < JOB_CHUNK / 256; ++u) {
+    long long i = i0 + u * 256 + threadIdx.x;
+    if (i >= total) break;
+    int c = (int)(i % C);
+    long long t = i / C;
+    int s_ = (int)(t % S); t /= S;
+    int r = (int)(t % R);
+    long long n = t / R;
+    float v = src[n * sn + r * sr + s_ * ss + c * sc] * inv;
+    long long d = n * pitch + (i - n * inner);
+    if (J[12]) ((float*)J[1])[d] = v;
+    else ((bf16_t*)J[1])[d] = f2bf(v);
+  }
+}
+
+extern "C" int ried_pack_jobs(const long long* jobs, const int* blockmap, int nblocks, hipStream_t stream) {
+  RIED_CHECK_ARG(jobs && blockmap && nblocks > 0, "ried_pack_jobs: bad arguments");
+  hipLaunchKernelGGL(pack_jobs_kernel, dim3(nblocks), dim3(256), 0, stream, jobs, blockmap);
+  RIED_CHECK_LAUNCH("ried_pack_jobs");
+  return RIED_OK;
+}
+
+#define WRED_JOB_WORDS 11
+// reduce job: slab, out, splitk, split_stride, taps, Cp, Cg, st, sp, sg, accumulate
+//   out[tap*st + p*sp + g*sg] (+)= sum_k slab[k*split_stride + (tap*Cp + p)*Cg + g]
+__global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const long long* __restrict__ jobs,
+                                                                const int* __restrict__ blockmap) {
+  const long long* J = jobs + (long long)blockmap[2 * blockIdx.x] * WRED_JOB_WORDS;
+  const float* slab = (const float*)J[0];
+  float* out = (float*)J[1];
+  const int splitk = (int)J[2], Cp = (int)J[5], Cg = (int)J[6];
+  const long long stride = J[3], st = J[7], sp = J[8], sg = J[9];
+  const long long total = J[4] * Cp * Cg;
+  long long i0 = (long long)blockmap[2 * blockIdx.x + 1] * JOB_CHUNK;
+#pragma unroll
+  for (int u = 0; u < JOB_CHUNK / 256; ++u) {
+    long long i = i0 + u * 256 + threadIdx.x;
+    if (i >= total) break;
+    float a = 0.f;
+    for (int k = 0; k < splitk; ++k) a += slab[k * stride + i];
+    int g = (int)(i % Cg);
+    long long t = i / Cg;
+    int p_ = (int)(t % Cp);
+    long long tap = t / Cp;
+    float* o = out + tap * st + p_ * sp + g * sg;
+    *o = J[10] ? *o + a : a;
+  }
+}
+
+extern "C" int ried_wgrad_reduce_jobs(const long long* jobs, const int* blockmap, int nblocks, hipStream_t stream) {
+  RIED_CHECK_ARG(jobs && blockmap && nblocks > 0, "ried_wgrad_reduce_jobs: bad arguments");
+  hipLaunchKernelGGL(wgrad_reduce_jobs_kernel, dim3(nblocks), dim3(256), 0, stream, jobs, blockmap);
+  RIED_CHECK_LAUNCH("ried_wgrad_reduce_jobs");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
 // BatchNorm2d, train mode (reference: src/rinet.py:187-193,199-205; torch semantics, eps 1e-5, momentum 0.1)
 // ---------------------------------------------------------------------------
 // Sum over rows of a [nrows][2][C] fp32 buffer for 32 channels per block: 256 threads = 32 channels x 8 row lanes.

@@ -40,7 +40,17 @@ class State:
 
     def __init__(self, sd: Dict[str, torch.Tensor], device="cuda"):
         self.device = device
-        names = [k for k in sd if is_trainable(k)]
+        names = []
+        for k in sd:          # q/k/v projection weights (and biases) of an attention layer are laid out back to
+            if not is_trainable(k) or k in names:      # back, so the fused [q; k; v] 1x1 conv reads them in place
+                continue
+            if k.endswith("query_conv.weight"):
+                base = k[:-len("query_conv.weight")]
+                group = [base + n + s for s in (".weight", ".bias") for n in ("query_conv", "key_conv", "value_conv")]
+                assert all(g in sd and g not in names for g in group), group
+                names += group
+            else:
+                names.append(k)
         offs, total = {}, 0
         for k in names:
             offs[k] = total
@@ -50,6 +60,7 @@ class State:
         self.p: Dict[str, torch.Tensor] = {}
         self.g: Dict[str, torch.Tensor] = {}
         self.b: Dict[str, torch.Tensor] = {}
+        self.offs = offs
         for k in names:
             n = sd[k].numel()
             self.p[k] = self.flat[offs[k]:offs[k] + n].view(sd[k].shape)
@@ -102,12 +113,13 @@ class Ctx:
         self.grad_arena: Optional[torch.Tensor] = None
         self._f32: List[Tuple[torch.Tensor, int, int]] = []
         self.stats_elems = 0          # fp32 arena zeroed at the start of every forward (BN sums)
-        self.sums_elems = 0           # fp32 arena zeroed at the start of every backward
         self.slab_elems = 0
         self.tmp_elems = 0
         self.f32_elems = 0            # shared fp32 scratch (BN backward partial rows, column sums)
         self._stats_req: List[Tuple[object, str, int]] = []
-        self._sums_req: List[Tuple[object, str, int]] = []
+        self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
+        self.wreds = ops.JobTable(11)      # every weight-gradient slab reduction: one launch (end_backward)
+        self._wred_slab: List[Tuple[int, int]] = []      # (job, slab offset) patched once the arena exists
 
     # activations
     def act(self, N, H, W, C, grad: Optional[bool] = None) -> Act:
@@ -125,13 +137,22 @@ class Ctx:
         self.stats_elems += (n + 3) // 4 * 4
         setattr(owner, attr + "_n", n)
 
-    def sums(self, owner, attr, n):
-        self._sums_req.append((owner, attr, self.sums_elems))
-        self.sums_elems += (n + 3) // 4 * 4
-        setattr(owner, attr + "_n", n)
+    def alloc_slab(self, n) -> int:
+        """Reserve n fp32 of the weight-gradient slab arena; returns the element offset."""
+        off = self.slab_elems
+        self.slab_elems += (n + 63) // 64 * 64
+        return off
 
-    def need_slab(self, n):
-        self.slab_elems = max(self.slab_elems, n)
+    def add_pack(self, src: torch.Tensor, dst: torch.Tensor, N, R, S, C, sn, sr, ss, sc, sigma=None, dst_pitch=None):
+        """dst[n][r][s][c] = src[n*sn + r*sr + s*ss + c*sc] / sigma, repacked by pack_all()."""
+        self.packs.add([src.data_ptr(), dst.data_ptr(), 0 if sigma is None else sigma.data_ptr(), N, R, S, C,
+                        sn, sr, ss, sc, R * S * C if dst_pitch is None else dst_pitch,
+                        1 if dst.dtype == F32 else 0], N * R * S * C)
+
+    def add_wgrad_reduce(self, slab_off, out: torch.Tensor, splitk, taps, Cp, Cg, st, sp, sg, accumulate=False):
+        j = self.wreds.add([0, out.data_ptr(), splitk, taps * Cp * Cg, taps, Cp, Cg, st, sp, sg, int(accumulate)],
+                           taps * Cp * Cg)
+        self._wred_slab.append((j, slab_off))
 
     def need_tmp(self, n):
         self.tmp_elems = max(self.tmp_elems, n)
@@ -149,12 +170,13 @@ class Ctx:
                 g.base, g.ptr = self.grad_arena, base + off
                 seen.add(id(g))
         self.stats_arena = torch.zeros(max(self.stats_elems, 4), dtype=F32, device=dev)
-        self.sums_arena = torch.zeros(max(self.sums_elems, 4), dtype=F32, device=dev)
         for owner, attr, off in self._stats_req:
             setattr(owner, attr, self.stats_arena[off:off + getattr(owner, attr + "_n")])
-        for owner, attr, off in self._sums_req:
-            setattr(owner, attr, self.sums_arena[off:off + getattr(owner, attr + "_n")])
         self.slab = torch.empty(max(self.slab_elems, 4), dtype=F32, device=dev)
+        for j, off in self._wred_slab:
+            self.wreds.rows[j][0] = self.slab.data_ptr() + 4 * off
+        self.packs.finalize(dev)
+        self.wreds.finalize(dev)
         self.tmp = torch.empty(max(self.tmp_elems, 8), dtype=torch.bfloat16, device=dev)
         self.f32 = torch.empty(max(self.f32_elems, 4), dtype=F32, device=dev)
 
@@ -162,11 +184,22 @@ class Ctx:
         assert N * H * W * C <= self.tmp.numel()
         return View(self.tmp, self.tmp.data_ptr(), C, C, N, H, W)
 
-    def zero_stats(self):
-        pass                     # BN partial-sum rows are fully overwritten by the conv epilogues
+    def slab_at(self, off) -> int:
+        return self.slab.data_ptr() + 4 * off
+
+    def pack_all(self):
+        """Rebuild every packed bf16 weight of the plan from the fp32 masters (forward and backward layouts)."""
+        ops.pack_jobs(self.packs)
+
+    def begin_forward(self):
+        self.pack_all()          # BN partial-sum rows need no clearing: the conv epilogues overwrite them
 
     def zero_backward(self):
         self.grad_arena.zero_()
+
+    def end_backward(self):
+        """Reduce the weight-gradient slabs of every layer into the master gradients (one launch)."""
+        ops.wgrad_reduce_jobs(self.wreds)
 
 
 # Deferred gradient pointers: Views handed out before Ctx.finalize() hold offsets.  Slices taken before
@@ -222,7 +255,10 @@ class ConvCore:
     """Weight handling shared by every bf16 conv / deconv layer: packing, forward, dgrad, wgrad."""
 
     def __init__(self, ctx: Ctx, wname: str, cin, cout, k, stride, pad, deconv: bool, xin: Slot, need_dx: bool,
-                 need_wgrad: bool = True):
+                 need_wgrad: bool = True, sigma: Optional[torch.Tensor] = None,
+                 wgrad_out: Optional[torch.Tensor] = None):
+        """sigma: device scalar the packed weights are divided by (spectral norm); wgrad_out: where the reduced
+        weight gradient goes (master layout; default: the parameter's slot in the state's gradient buffer)."""
         self.ctx, self.wname = ctx, wname
         self.cin, self.cout = cin, cout
         self.kh, self.kw = _pair(k)
@@ -248,26 +284,22 @@ class ConvCore:
             big = not (cg <= 64 and cp <= 64)
             tiles = ((cg + 127) // 128) * ((cp + 127) // 128) if big else 1
             self.splitk = _splitk(tiles * taps, kp)
-            ctx.need_slab(self.splitk * taps * cin * cout)
-
-    def weight(self) -> torch.Tensor:
-        return self.ctx.st.p[self.wname]
-
-    def pack_fwd(self, sigma=None):
-        ci, co, kh, kw = self.cin, self.cout, self.kh, self.kw
-        t = kh * kw
-        if self.deconv:   # master (Cin,Cout,kh,kw) -> [Cout][kh][kw][Cin]
-            ops.pack_weight(self.weight(), self.wp, co, kh, kw, ci, t, kw, 1, co * t, sigma)
-        else:             # master (Cout,Cin,kh,kw) -> [Cout][kh][kw][Cin]
-            ops.pack_weight(self.weight(), self.wp, co, kh, kw, ci, ci * t, kw, 1, t, sigma)
-
-    def pack_bwd(self, sigma=None):
-        ci, co, kh, kw = self.cin, self.cout, self.kh, self.kw
-        t = kh * kw
-        if self.deconv:   # -> [Cin][kh][kw][Cout]
-            ops.pack_weight(self.weight(), self.wpt, ci, kh, kw, co, co * t, kw, 1, t, sigma)
-        else:
-            ops.pack_weight(self.weight(), self.wpt, ci, kh, kw, co, t, kw, 1, ci * t, sigma)
+            self.slab_off = ctx.alloc_slab(self.splitk * taps * cin * cout)
+            out = ctx.st.g[wname] if wgrad_out is None else wgrad_out
+            if deconv:    # slab [taps][Cp=cin][Cg=cout] -> master (Cin,Cout,kh,kw)
+                ctx.add_wgrad_reduce(self.slab_off, out, self.splitk, taps, cin, cout, 1, cout * taps, taps)
+            else:         # slab [taps][Cp=cout][Cg=cin] -> master (Cout,Cin,kh,kw)
+                ctx.add_wgrad_reduce(self.slab_off, out, self.splitk, taps, cout, cin, 1, cin * taps, taps)
+        if ctx.st is not None:
+            w, t, kh, kw = ctx.st.p[wname], taps, self.kh, self.kw
+            if deconv:    # master (Cin,Cout,kh,kw) -> [Cout][kh][kw][Cin]; backward layout [Cin][kh][kw][Cout]
+                ctx.add_pack(w, self.wp, cout, kh, kw, cin, t, kw, 1, cout * t, sigma)
+                if self.wpt is not None:
+                    ctx.add_pack(w, self.wpt, cin, kh, kw, cout, cout * t, kw, 1, t, sigma)
+            else:         # master (Cout,Cin,kh,kw) -> [Cout][kh][kw][Cin]; backward layout [Cin][kh][kw][Cout]
+                ctx.add_pack(w, self.wp, cout, kh, kw, cin, cin * t, kw, 1, t, sigma)
+                if self.wpt is not None:
+                    ctx.add_pack(w, self.wpt, cin, kh, kw, cout, t, kw, 1, cin * t, sigma)
 
     def conv(self, y: View, **kw):
         ops.conv2d(self.xin.v, self.wp, y, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
@@ -278,18 +310,15 @@ class ConvCore:
         ops.conv2d(dy, self.wpt, dx, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
                    transposed=not self.deconv, accumulate=True)
 
-    def wgrad(self, dy: View, out: torch.Tensor, x: Optional[View] = None, accumulate=False):
-        """out (master layout) (+)= weight gradient."""
-        ctx, t = self.ctx, self.kh * self.kw
+    def wgrad(self, dy: View, x: Optional[View] = None):
+        """Split-K partial weight gradients into this layer's slab; Ctx.end_backward() reduces all layers."""
+        ctx = self.ctx
         x = self.xin.v if x is None else x
+        slab = ctx.slab_at(self.slab_off)
         if self.deconv:
-            ops.conv2d_wgrad(dy, x, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, ctx.slab, self.splitk)
-            ops.wgrad_reduce(ctx.slab, self.splitk, t, self.cin, self.cout, out, 1, self.cout * t, t,
-                             accumulate=accumulate)
+            ops.conv2d_wgrad(dy, x, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, slab, self.splitk)
         else:
-            ops.conv2d_wgrad(x, dy, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, ctx.slab, self.splitk)
-            ops.wgrad_reduce(ctx.slab, self.splitk, t, self.cout, self.cin, out, 1, self.cin * t, t,
-                             accumulate=accumulate)
+            ops.conv2d_wgrad(x, dy, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, slab, self.splitk)
 
 
 class ConvBN:
@@ -317,7 +346,6 @@ class ConvBN:
 
     def forward(self):
         ctx, c, st = self.ctx, self.core, self.ctx.st
-        c.pack_fwd()
         if ctx.training:
             c.conv(self.raw, stats=self.stats)
             ops.bn_finalize(self.stats, self.stat_rows, c.cout, self.raw.npix, self.save,
@@ -335,9 +363,8 @@ class ConvBN:
         draw = ctx.tmp_view(c.N, c.Ho, c.Wo, c.cout)
         ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
                         ctx.f32, st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True)
-        c.wgrad(draw, st.g[c.wname])
+        c.wgrad(draw)
         if c.need_dx:
-            c.pack_bwd()
             c.dgrad(draw, c.xin.g)
 
 
@@ -389,13 +416,11 @@ class ConvPlain:
         self.core = ConvCore(ctx, wname, cin, cout, 1, 1, 0, False, xin, True)
 
     def forward(self):
-        self.core.pack_fwd()
         self.core.conv(self.out.v)
 
     def backward(self):
-        c, st = self.core, self.ctx.st
-        c.wgrad(self.out.g, st.g[c.wname])
-        c.pack_bwd()
+        c = self.core
+        c.wgrad(self.out.g)
         c.dgrad(self.out.g, c.xin.g)
 
 
@@ -610,8 +635,7 @@ class Generator:
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         assert x.shape == (self.N, 1, self.H, self.W) and x.dtype == F32 and x.is_contiguous()
         self.x = x
-        if self.ctx.training:
-            self.ctx.zero_stats()
+        self.ctx.begin_forward()
         self.conv1.forward(x)
         self.body.forward()
         ops.out_conv_fwd(x, self.hlast.v, self.st.p["out_conv.weight"], self.out)
@@ -625,6 +649,7 @@ class Generator:
                          self.st.g["out_conv.weight"])
         self.body.backward()
         self.conv1.backward()
+        self.ctx.end_backward()
 
 
 # --------------------------------------------------------------------------- discriminator
@@ -638,27 +663,31 @@ class SNConv:
         self.K = cin * 9
         self.sigma = torch.ones(1, dtype=F32, device=dev)
         self.scratch = torch.zeros(self.K + cout + 2, dtype=F32, device=dev)    # sn_sigma: [K + R]; sn_backward: [1]
-        if not first:
-            self.core = ConvCore(ctx, prefix + ".weight_orig", cin, cout, 3, stride, 1, False, xin, True)
         N, Ho, Wo, _ = out.shape
+        self.dwsn = torch.empty(cout * self.K, dtype=F32, device=dev) if ctx.grads else None
+        if not first:
+            self.core = ConvCore(ctx, prefix + ".weight_orig", cin, cout, 3, stride, 1, False, xin, True,
+                                 sigma=self.sigma, wgrad_out=self.dwsn)
         if ctx.grads:
             ctx.need_tmp(N * Ho * Wo * cout)
             ctx.need_f32(ops.colsum_scratch_floats(cout))
             if first:
                 ctx.need_f32(ops.conv_c1_wgrad_scratch_floats(cout))
-            self.dwsn = torch.empty(cout * self.K, dtype=F32, device=dev)
         self.x_img: Optional[torch.Tensor] = None
+
+    def compute_sigma(self):
+        """One power iteration (training) and sigma = u^T W v; must precede Ctx.pack_all(), which divides by it."""
+        st, p = self.ctx.st, self.prefix
+        ops.sn_sigma(st.p[p + ".weight_orig"], self.cout, self.K, st.b[p + ".weight_u"], st.b[p + ".weight_v"],
+                     self.sigma, self.scratch, power_iter=self.ctx.training)
 
     def forward(self, x_img: Optional[torch.Tensor] = None):
         st, p = self.ctx.st, self.prefix
-        w = st.p[p + ".weight_orig"]
-        ops.sn_sigma(w, self.cout, self.K, st.b[p + ".weight_u"], st.b[p + ".weight_v"], self.sigma, self.scratch,
-                     power_iter=self.ctx.training)
         if self.first:
             self.x_img = x_img
-            ops.conv_c1_fwd(x_img, w, self.out.v, self.stride, sigma=self.sigma, bias=st.p[p + ".bias"], act=2)
+            ops.conv_c1_fwd(x_img, st.p[p + ".weight_orig"], self.out.v, self.stride, sigma=self.sigma,
+                            bias=st.p[p + ".bias"], act=2)
         else:
-            self.core.pack_fwd(self.sigma)
             self.core.conv(self.out.v, bias=st.p[p + ".bias"], act=2)
 
     def backward(self, n0: int, n1: int, wgrad: bool, dimg: Optional[torch.Tensor] = None):
@@ -674,15 +703,18 @@ class SNConv:
                 self.dwsn.zero_()
                 ops.conv_c1_wgrad(self.x_img[n0:n1], dpre, self.stride, self.dwsn, ctx.f32)
             else:
-                self.core.wgrad(dpre, self.dwsn, x=self.core.xin.images(n0, n1).v)
-            ops.sn_backward(self.dwsn, st.p[p + ".weight_orig"], st.b[p + ".weight_u"], st.b[p + ".weight_v"],
-                            self.sigma, self.cout, self.K, st.g[p + ".weight_orig"], self.scratch)
+                self.core.wgrad(dpre, x=self.core.xin.images(n0, n1).v)
         if self.first:
             if dimg is not None:
                 ops.conv_c1_dgrad(dpre, st.p[p + ".weight_orig"], dimg, sigma=self.sigma, accumulate=True)
         else:
-            self.core.pack_bwd(self.sigma)
             self.core.dgrad(dpre, self.core.xin.images(n0, n1).g)
+
+    def finish_wgrad(self):
+        """After Ctx.end_backward(): gradient of W/sigma (in dwsn) -> gradient of weight_orig."""
+        st, p = self.ctx.st, self.prefix
+        ops.sn_backward(self.dwsn, st.p[p + ".weight_orig"], st.b[p + ".weight_u"], st.b[p + ".weight_v"],
+                        self.sigma, self.cout, self.K, st.g[p + ".weight_orig"], self.scratch)
 
 
 class Attn:
@@ -698,8 +730,13 @@ class Attn:
         self.cq = 2 * self.d + C
         self.qkv = Slot(ctx.act(N, H, W, self.cq))
         self.wp = torch.empty(self.cq * C, dtype=torch.bfloat16, device=dev)
-        self.wcat = torch.empty(self.cq, C, dtype=F32, device=dev)          # [q; k; v] projection weights
-        self.bias = torch.empty(self.cq, dtype=F32, device=dev)
+        st = ctx.st                  # State lays q, k, v weights (and biases) out back to back: views, no copies
+        ow, ob = st.offs[prefix + ".query_conv.weight"], st.offs[prefix + ".query_conv.bias"]
+        assert st.offs[prefix + ".value_conv.weight"] == ow + 2 * self.d * C
+        assert st.offs[prefix + ".value_conv.bias"] == ob + 2 * self.d
+        self.wcat = st.flat[ow:ow + self.cq * C].view(self.cq, C)           # [q; k; v] projection weights
+        self.bias = st.flat[ob:ob + self.cq]
+        ctx.add_pack(self.wcat, self.wp, self.cq, 1, 1, C, C, 1, 1, 1)
         self.S = torch.empty(N * self.n * self.n, dtype=F32, device=dev)
         self.P = torch.empty(N * self.n * self.n, dtype=torch.bfloat16, device=dev)
         self.O = ops.new_view(N, H, W, C, dev)
@@ -707,11 +744,13 @@ class Attn:
             self.wpt = torch.empty(self.cq * C, dtype=torch.bfloat16, device=dev)
             self.dS = torch.empty(N * self.n * self.n, dtype=torch.bfloat16, device=dev)
             self.dO = ops.new_view(N, H, W, C, dev)
-            self.dw = torch.empty(self.cq * C, dtype=F32, device=dev)
-            self.db = torch.zeros(self.cq, dtype=F32, device=dev)
+            self.dw = st.flat_grad[ow:ow + self.cq * C]
+            self.db = st.flat_grad[ob:ob + self.cq]
+            ctx.add_pack(self.wcat, self.wpt, C, 1, 1, self.cq, 1, 1, 1, C)   # [C][1][1][cq] for the data gradient
             kp = N * self.n
             self.splitk = _splitk(((C + 127) // 128) * ((self.cq + 127) // 128), kp)
-            ctx.need_slab(self.splitk * self.cq * C)
+            self.slab_off = ctx.alloc_slab(self.splitk * self.cq * C)
+            ctx.add_wgrad_reduce(self.slab_off, self.dw, self.splitk, 1, self.cq, C, 1, C, 1)
             ctx.need_f32(ops.colsum_scratch_floats(self.cq))
 
     def _names(self):
@@ -721,10 +760,6 @@ class Attn:
 
     def forward(self):
         st, C, d, n, N = self.ctx.st, self.C, self.d, self.n, self.N
-        for name, c0, c1 in self._names():
-            self.wcat[c0:c1].copy_(st.p[name + ".weight"].view(c1 - c0, C))
-            self.bias[c0:c1].copy_(st.p[name + ".bias"])
-        ops.pack_weight(self.wcat, self.wp, self.cq, 1, 1, C, C, 1, 1, 1)
         x, qkv = self.xin.v, self.qkv.v
         ops.conv2d(x, self.wp, qkv, 1, 1, 1, 1, 0, 0, bias=self.bias)
         q, k, v = qkv.ptr, qkv.ptr + 2 * d, qkv.ptr + 4 * d
@@ -762,15 +797,9 @@ class Attn:
         ops.bgemm(k, ld, bs, 1, dS, n, n * n, 0, d, n, n, N, dq, ld, bs)
         # dk[j][e] = sum_i dS[i][j] q[i][e] : m = e (A = q stored [i][e]), n = j (B = dS stored [i][j])
         ops.bgemm(q, ld, bs, 1, dS, n, n * n, 1, d, n, n, N, dk, ld, bs)
-        if wgrad:
-            self.db.zero_()
+        if wgrad:             # bias and weight gradients land directly in the state's (zeroed) gradient buffer
             ops.colsum(qkv.g, self.db, self.ctx.f32)
-            ops.conv2d_wgrad(xin.v, qkv.g, 1, 1, 1, 1, 0, 0, self.ctx.slab, self.splitk)
-            ops.wgrad_reduce(self.ctx.slab, self.splitk, 1, self.cq, C, self.dw, 1, C, 1)
-            for name, c0, c1 in self._names():
-                st.g[name + ".weight"].view(-1).add_(self.dw[c0 * C:c1 * C])
-                st.g[name + ".bias"].add_(self.db[c0:c1])
-        ops.pack_weight(self.wcat, self.wpt, C, 1, 1, self.cq, 1, 1, 1, C)   # [C][1][1][cq] for the data gradient
+            ops.conv2d_wgrad(xin.v, qkv.g, 1, 1, 1, 1, 0, 0, self.ctx.slab_at(self.slab_off), self.splitk)
         ops.conv2d(qkv.g, self.wpt, xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True)
 
 
@@ -810,6 +839,10 @@ class Discriminator:
     def forward(self, x_img: torch.Tensor) -> Slot:
         """x_img: fp32 (N,1,H,W).  Returns the last activation (N, H/16, W/16, 512) NHWC bf16."""
         assert x_img.shape == (self.N, 1, self.H, self.W) and x_img.dtype == F32 and x_img.is_contiguous()
+        for l in self.layers:
+            if isinstance(l, SNConv):
+                l.compute_sigma()
+        self.ctx.begin_forward()
         for i, l in enumerate(self.layers):
             if i == 0:
                 l.forward(x_img)
@@ -825,6 +858,11 @@ class Discriminator:
                 l.backward(n0, n1, wgrad, dimg)
             else:
                 l.backward(n0, n1, wgrad)
+        if wgrad:
+            self.ctx.end_backward()
+            for l in self.layers:
+                if isinstance(l, SNConv):
+                    l.finish_wgrad()
 
     def output_nchw(self) -> torch.Tensor:
         """(N, 8192-like) fp32 in the reference's flattening order (C, H, W) (src/rinet.py:31)."""

@@ -74,9 +74,10 @@ def conv2d(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed
                     _stream())
 
 
-def conv2d_wgrad(g: View, p: View, kh, kw, sh, sw, ph, pw, slab: torch.Tensor, splitk: int):
+def conv2d_wgrad(g: View, p: View, kh, kw, sh, sw, ph, pw, slab, splitk: int):
+    """slab: fp32 tensor or raw device address of [splitk][kh*kw][p.C][g.C]."""
     lib.ried_conv2d_wgrad(g.ptr, g.ld, g.C, g.N, g.H, g.W, p.ptr, p.ld, p.C, p.H, p.W, kh, kw, sh, sw, ph, pw,
-                          _p(slab), splitk, _stream())
+                          slab if isinstance(slab, int) else _p(slab), splitk, _stream())
 
 
 def wgrad_reduce(slab, splitk, taps, Cp, Cg, out: torch.Tensor, st, sp, sg, scale=1.0, accumulate=False):
@@ -91,6 +92,45 @@ def bgemm(A, lda, bsa, a_tr, B, ldb, bsb, b_tr, M, N, K, batch, out, ldc, bsc, o
 
 def pack_weight(src: torch.Tensor, dst: torch.Tensor, N, R, S, C, sn, sr, ss, sc, sigma=None):
     lib.ried_pack_weight(_p(src), _p(dst), N, R, S, C, sn, sr, ss, sc, _p(sigma), _stream())
+
+
+JOB_CHUNK = 2048
+
+
+class JobTable:
+    """Host-side builder of a device job table for ried_pack_jobs / ried_wgrad_reduce_jobs: rows of int64 words
+    (pointers and integers) plus the (job, chunk) map that assigns 2048-element chunks to blocks."""
+
+    def __init__(self, words: int):
+        self.words, self.rows, self.totals = words, [], []
+        self.jobs = self.blockmap = None
+
+    def add(self, row, total: int) -> int:
+        assert len(row) == self.words and self.jobs is None
+        self.rows.append([int(v) for v in row])
+        self.totals.append(int(total))
+        return len(self.rows) - 1
+
+    def finalize(self, device):
+        import numpy as np
+        if not self.rows:
+            return
+        bm = []
+        for j, t in enumerate(self.totals):
+            bm.extend((j, c) for c in range((t + JOB_CHUNK - 1) // JOB_CHUNK))
+        self.jobs = torch.from_numpy(np.asarray(self.rows, dtype=np.int64)).to(device)
+        self.blockmap = torch.from_numpy(np.asarray(bm, dtype=np.int32).reshape(-1)).to(device)
+        self.nblocks = len(bm)
+
+
+def pack_jobs(t: JobTable):
+    if t.jobs is not None:
+        lib.ried_pack_jobs(_p(t.jobs), _p(t.blockmap), t.nblocks, _stream())
+
+
+def wgrad_reduce_jobs(t: JobTable):
+    if t.jobs is not None:
+        lib.ried_wgrad_reduce_jobs(_p(t.jobs), _p(t.blockmap), t.nblocks, _stream())
 
 
 # --------------------------------------------------------------------------- batch norm

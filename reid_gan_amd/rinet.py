@@ -79,8 +79,7 @@ class _Runner:
 
     def forward(self, x):
         ops.nchw_to_nhwc(x.contiguous().to(F32), self.a_in.v)
-        if self.ctx.training:
-            self.ctx.zero_stats()
+        self.ctx.begin_forward()
         self.plan.forward()
         ops.nhwc_to_nchw(self.a_out.v, self.y)
         return self.y.clone()
@@ -90,6 +89,7 @@ class _Runner:
         self.state.zero_grad()
         ops.nchw_to_nhwc(dy.to(F32), self.a_out.g)
         self.plan.backward()
+        self.ctx.end_backward()
         if not need_dx:
             return None
         ops.nhwc_to_nchw(self.a_in.g, self.dx)
@@ -350,6 +350,8 @@ class _SNRunner:
 
     def forward(self, x):
         x = x.contiguous().to(F32)
+        self.layer.compute_sigma()
+        self.ctx.begin_forward()
         if self.first:
             self.x = x
             self.layer.forward(x)
@@ -366,8 +368,11 @@ class _SNRunner:
         if self.first:
             self.dx.zero_()
             self.layer.backward(0, self.N, True, self.dx if need_dx else None)
+            self.layer.finish_wgrad()
             return self.dx.clone() if need_dx else None
         self.layer.backward(0, self.N, True)
+        self.ctx.end_backward()
+        self.layer.finish_wgrad()
         if not need_dx:
             return None
         ops.nhwc_to_nchw(self.a_in.g, self.dx)

@@ -112,12 +112,13 @@ def _run_block(name, N, hw, golden=None):
     plan = build(ctx, a_in, a_out)
     ctx.finalize()
     ops.nchw_to_nhwc(xin.to(DEV), a_in.v)
-    ctx.zero_stats()
+    ctx.begin_forward()
     plan.forward()
     got_y = a_out.v.torch().float().cpu().permute(0, 3, 1, 2)
     ctx.zero_backward(); st.zero_grad()
     ops.nchw_to_nhwc(gw.to(DEV), a_out.g)
     plan.backward()
+    ctx.end_backward()
     torch.cuda.synchronize()
     got_dx = a_in.g.torch().float().cpu().permute(0, 3, 1, 2)
     _close(got_y, y.detach(), name + " y")

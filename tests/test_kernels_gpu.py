@@ -164,6 +164,43 @@ def test_deconv_wgrad():
     close(out.cpu(), ref, 3e-3, "dW")
 
 
+def test_job_table_pack_and_reduce_match_single_calls():
+    """One launch over a job table = the per-layer calls, bit for bit (same arithmetic per element)."""
+    g = torch.Generator().manual_seed(5)
+    jobs_p, jobs_r = ops.JobTable(13), ops.JobTable(11)
+    keep, checks = [], []
+    sigma = torch.tensor([1.7], device=DEV)
+    for n, (co, ci, kh, kw) in enumerate([(64, 32, 3, 3), (96, 192, 4, 4), (8, 8, 1, 1), (520, 24, 1, 7)]):
+        t = kh * kw
+        w = torch.randn(co, ci, kh, kw, generator=g).to(DEV)
+        ref = torch.empty(co * t * ci, dtype=torch.bfloat16, device=DEV)
+        got = torch.full_like(ref, float("nan"))
+        sg = sigma if n % 2 else None
+        ops.pack_weight(w, ref, co, kh, kw, ci, ci * t, kw, 1, t, sg)
+        jobs_p.add([w.data_ptr(), got.data_ptr(), 0 if sg is None else sg.data_ptr(), co, kh, kw, ci, ci * t, kw, 1, t,
+                    kh * kw * ci, 0], co * t * ci)
+        splitk = 3 + n
+        slab = torch.randn(splitk, t, co, ci, generator=g).to(DEV)
+        oref = torch.zeros(co, ci, kh, kw, device=DEV)
+        ogot = torch.full_like(oref, 0.5)
+        ops.wgrad_reduce(slab, splitk, t, co, ci, oref, 1, ci * t, t)
+        jobs_r.add([slab.data_ptr(), ogot.data_ptr(), splitk, t * co * ci, t, co, ci, 1, ci * t, t, 0], t * co * ci)
+        keep += [w, slab]
+        checks += [(ref, got), (oref, ogot)]
+    # an fp32 destination with a row pitch (a [rows][pitch] matrix filled in column blocks)
+    src = torch.randn(40, 24, generator=g).to(DEV)
+    dst = torch.zeros(40, 64, device=DEV)
+    jobs_p.add([src.data_ptr(), dst.data_ptr() + 4 * 8, 0, 40, 1, 1, 24, 24, 1, 1, 1, 64, 1], 40 * 24)
+    jobs_p.finalize(DEV); jobs_r.finalize(DEV)
+    ops.pack_jobs(jobs_p)
+    ops.wgrad_reduce_jobs(jobs_r)
+    torch.cuda.synchronize()
+    for a, b in checks:
+        assert torch.equal(a, b)
+    assert torch.equal(dst[:, 8:32], src) and dst[:, :8].abs().sum() == 0 and dst[:, 32:].abs().sum() == 0
+
+
+
 @pytest.mark.parametrize("a_tr,b_tr", [(0, 0), (1, 0), (1, 1), (0, 1)])
 @pytest.mark.parametrize("M,N,K", [(256, 256, 32), (64, 64, 64), (32, 256, 256), (512, 64, 64), (256, 1024, 32)])
 def test_bgemm(a_tr, b_tr, M, N, K):
