@@ -142,13 +142,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const long long*
   const int splitk = (int)J[2], Cp = (int)J[5], Cg = (int)J[6];
   const long long stride = J[3], st = J[7], sp = J[8], sg = J[9];
   const long long total = J[4] * Cp * Cg;
-  long long i0 = (long long)blockmap[2 * blockIdx.x + 1] * JOB_CHUNK;
+  const long long i0 = (long long)blockmap[2 * blockIdx.x + 1] * JOB_CHUNK + threadIdx.x;
+  constexpr int U = JOB_CHUNK / 256;
+  float acc[U];
 #pragma unroll
-  for (int u = 0; u < JOB_CHUNK / 256; ++u) {
-    long long i = i0 + u * 256 + threadIdx.x;
+  for (int u = 0; u < U; ++u) acc[u] = 0.f;
+  for (int k = 0; k < splitk; ++k) {            // U independent loads in flight per split
+    const float* s = slab + k * stride + i0;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (i0 + u * 256 < total) acc[u] += s[u * 256];
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    long long i = i0 + u * 256;
     if (i >= total) break;
-    float a = 0.f;
-    for (int k = 0; k < splitk; ++k) a += slab[k * stride + i];
+    float a = acc[u];
     int g = (int)(i % Cg);
     long long t = i / Cg;
     int p_ = (int)(t % Cp);
@@ -168,31 +177,35 @@ extern "C" int ried_wgrad_reduce_jobs(const long long* jobs, const int* blockmap
 // ---------------------------------------------------------------------------
 // BatchNorm2d, train mode (reference: src/rinet.py:187-193,199-205; torch semantics, eps 1e-5, momentum 0.1)
 // ---------------------------------------------------------------------------
-// Sum over rows of a [nrows][2][C] fp32 buffer for 32 channels per block: 256 threads = 32 channels x 8 row lanes.
-// Returns (sum, sum2) for channel c in the threads with ty == 0.
+// Sum over rows of a [nrows][2][C] fp32 buffer for 32 channels per block: 1024 threads = 32 channels x 32 row
+// lanes, four rows in flight per lane.  Returns (sum, sum2) for channel c in the threads with ty == 0.
+#define ROWRED_THREADS 1024
 __device__ __forceinline__ void reduce_rows_2c(const float* __restrict__ part, int nrows, int C, int c, int ty,
-                                               float& s0, float& s1, float (*sh)[8][32]) {
+                                               float& s0, float& s1, float (*sh)[32][32]) {
   float a = 0.f, b = 0.f;
-  if (c < C)
-    for (int r = ty; r < nrows; r += 8) {
+  if (c < C) {
+#pragma unroll 4
+    for (int r = ty; r < nrows; r += 32) {
       a += part[(long long)r * 2 * C + c];
       b += part[(long long)r * 2 * C + C + c];
     }
+  }
   sh[0][ty][threadIdx.x & 31] = a;
   sh[1][ty][threadIdx.x & 31] = b;
   __syncthreads();
   s0 = 0.f; s1 = 0.f;
   if (ty == 0) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { s0 += sh[0][k][threadIdx.x & 31]; s1 += sh[1][k][threadIdx.x & 31]; }
+    for (int k = 0; k < 32; ++k) { s0 += sh[0][k][threadIdx.x & 31]; s1 += sh[1][k][threadIdx.x & 31]; }
   }
 }
 
 // stats: [nrows][2][C] per-block partial sum / sum of squares from the conv epilogue.  save: [2][C] mean, invstd.
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int nrows, int C, float count, float eps,
-                                   float momentum, float* __restrict__ save, float* __restrict__ running_mean,
-                                   float* __restrict__ running_var, long long* __restrict__ nbt) {
-  __shared__ float sh[2][8][32];
+__global__ __launch_bounds__(ROWRED_THREADS) void bn_finalize_kernel(
+    const float* __restrict__ stats, int nrows, int C, float count, float eps, float momentum,
+    float* __restrict__ save, float* __restrict__ running_mean, float* __restrict__ running_var,
+    long long* __restrict__ nbt) {
+  __shared__ float sh[2][32][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
   float s0, s1;
   reduce_rows_2c(stats, nrows, C, c, ty, s0, s1, sh);
@@ -214,8 +227,8 @@ extern "C" int ried_bn_finalize(const float* stats, int nrows, int C, long long 
                                 float* save, float* running_mean, float* running_var,
                                 long long* num_batches_tracked, hipStream_t stream) {
   RIED_CHECK_ARG(stats && save && C > 0 && count > 0 && nrows > 0, "ried_bn_finalize: bad arguments");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, stream, stats, nrows, C, (float)count,
-                     eps, momentum, save, running_mean, running_var, num_batches_tracked);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(ROWRED_THREADS), 0, stream, stats, nrows, C,
+                     (float)count, eps, momentum, save, running_mean, running_var, num_batches_tracked);
   RIED_CHECK_LAUNCH("ried_bn_finalize");
   return RIED_OK;
 }
@@ -232,23 +245,49 @@ extern "C" int ried_bn_eval_stats(const float* rm, const float* rv, int C, float
   return RIED_OK;
 }
 
+// Pixel-linear mapping of the per-channel kernels below: a thread keeps one 8-channel chunk c for its whole loop
+// (its per-channel constants live in registers) and walks pixels pl, pl + step, ...; threads beyond the last
+// whole pixel of a block pass stay idle.  No integer division inside the loops.
+struct ChanWalk {
+  int c;                // first channel of the chunk
+  long long p, step;    // first pixel, pixel stride
+  bool active;
+  __device__ __forceinline__ ChanWalk(int C) {
+    const int CC = C >> 3, PPB = blockDim.x / CC;           // PPB >= 1: C <= 8 * blockDim.x (host-checked)
+    const int pl = threadIdx.x / CC;
+    c = (threadIdx.x - pl * CC) << 3;
+    active = pl < PPB;
+    p = (long long)blockIdx.x * PPB + pl;
+    step = (long long)gridDim.x * PPB;
+  }
+};
+static inline int chan_grid(long long npix, int C, int iters, int cap) {
+  int ppb = EW_THREADS / (C >> 3);
+  return ew_grid(npix, ppb * iters, cap);
+}
+
 // y = relu(gamma*(x-mean)*invstd + beta) [+ y]
-__global__ void bn_apply_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy,
-                                long long npix, int C, const float* __restrict__ save, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, int relu, int accumulate) {
-  const int CC = C >> 3;
-  long long total = npix * CC;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    long long p = i / CC;
-    int c = (int)(i - p * CC) << 3;
-    float f[8];
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
+    const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy, long long npix, int C,
+    const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+    int accumulate) {
+  ChanWalk w(C);
+  if (!w.active) return;
+  const int c = w.c;
+  float a[8], b[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    a[q] = gamma[c + q] * save[C + c + q];
+    b[q] = beta[c + q] - save[c + q] * a[q];
+  }
+#pragma unroll 2
+  for (long long p = w.p; p < npix; p += w.step) {
+    float f[8], o[8];
     unpack8(ld8(x + p * ldx + c), f);
-    float o[8];
     if (accumulate) unpack8(ld8(y + p * ldy + c), o);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float a = gamma[c + q] * save[C + c + q];
-      float v = (f[q] - save[c + q]) * a + beta[c + q];
+      float v = f[q] * a[q] + b[q];
       if (relu) v = fmaxf(v, 0.f);
       f[q] = accumulate ? v + o[q] : v;
     }
@@ -261,88 +300,95 @@ extern "C" int ried_bn_apply(const void* x, long long ldx, void* y, long long ld
                              hipStream_t stream) {
   CHECK_VIEW("ried_bn_apply", x, ldx, C);
   CHECK_VIEW("ried_bn_apply", y, ldy, C);
-  RIED_CHECK_ARG(save && gamma && beta && npix > 0, "ried_bn_apply: bad arguments");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS)), dim3(EW_THREADS), 0, stream,
+  RIED_CHECK_ARG(save && gamma && beta && npix > 0 && C <= 8 * EW_THREADS, "ried_bn_apply: bad arguments");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(chan_grid(npix, C, 2, 8192)), dim3(EW_THREADS), 0, stream,
                      (const bf16_t*)x, ldx, (bf16_t*)y, ldy, npix, C, save, gamma, beta, relu, accumulate);
   RIED_CHECK_LAUNCH("ried_bn_apply");
   return RIED_OK;
 }
 
-// backward pass 1: sums[0][c] = sum g, sums[1][c] = sum g*xhat, g = dy * [bn(x) > 0]
-__global__ void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x,
-                                     long long ldx, long long npix, int C, const float* __restrict__ save,
-                                     const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-                                     float* __restrict__ sums) {
-  extern __shared__ float lsum[];                 // [2][C]
-  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) lsum[i] = 0.f;
-  __syncthreads();
-  const int CC = C >> 3;
-  // a thread keeps the same channel chunk across its loop when the stride is a multiple of CC
-  // (threads beyond the largest multiple of CC stay idle so no element is skipped)
-  long long stride = (long long)gridDim.x * blockDim.x / CC * CC;
-  long long total = npix * CC;
-  long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i < total && i < stride) {
-    int c = (int)(i % CC) << 3;
-    float a[8], b[8], mean[8], istd[8], s1[8], s2[8];
+// backward pass 1: per-block partial sums[0][c] = sum g, sums[1][c] = sum g*xhat, g = dy * [bn(x) > 0]
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
+    const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx, long long npix, int C,
+    const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+    float* __restrict__ sums) {
+  __shared__ float red[EW_THREADS][17];           // per-thread partials, padded against bank conflicts
+  ChanWalk w(C);
+  const int c = w.c;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  if (w.active) {
+    float a[8], b[8], mean[8], istd[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       mean[q] = save[c + q]; istd[q] = save[C + c + q];
       a[q] = gamma[c + q] * istd[q]; b[q] = beta[c + q];
-      s1[q] = 0.f; s2[q] = 0.f;
     }
-    for (; i < total; i += stride) {
-      long long p = i / CC;
+#pragma unroll 2
+    for (long long p = w.p; p < npix; p += w.step) {
       float g[8], xv[8];
       unpack8(ld8(dy + p * lddy + c), g);
       unpack8(ld8(x + p * ldx + c), xv);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        float xh = (xv[q] - mean[q]) * istd[q];
-        float pre = (xv[q] - mean[q]) * a[q] + b[q];
-        float gg = (!relu || pre > 0.f) ? g[q] : 0.f;
-        s1[q] += gg; s2[q] += gg * xh;
+        float d = xv[q] - mean[q];
+        float gg = (!relu || d * a[q] + b[q] > 0.f) ? g[q] : 0.f;
+        s1[q] += gg; s2[q] += gg * (d * istd[q]);
       }
     }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { atomicAdd(&lsum[c + q], s1[q]); atomicAdd(&lsum[C + c + q], s2[q]); }
   }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { red[threadIdx.x][q] = s1[q]; red[threadIdx.x][8 + q] = s2[q]; }
   __syncthreads();
-  float* row = sums + (long long)blockIdx.x * 2 * C;            // one partial row per block, no global atomics
-  for (int j = threadIdx.x; j < 2 * C; j += blockDim.x) row[j] = lsum[j];
+  // channel j of statistic k: sum over the block's pixel lanes of the thread partials
+  const int CC = C >> 3, PPB = EW_THREADS / CC;
+  float* row = sums + (long long)blockIdx.x * 2 * C;
+  for (int j = threadIdx.x; j < 2 * C; j += EW_THREADS) {
+    int k = j >= C, ch = j - k * C;
+    int t0 = ch >> 3, q = (ch & 7) + 8 * k;
+    float acc = 0.f;
+    for (int pl = 0; pl < PPB; ++pl) acc += red[pl * CC + t0][q];
+    row[j] = acc;
+  }
 }
 
 // backward pass 2: dx = gamma*invstd*(g - s1/n - xhat*s2/n)
-__global__ void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x,
-                                    long long ldx, bf16_t* __restrict__ dx, long long lddx, long long npix, int C,
-                                    const float* __restrict__ save, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, int relu, const float* __restrict__ sums) {
-  const int CC = C >> 3;
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx,
+    bf16_t* __restrict__ dx, long long lddx, long long npix, int C, const float* __restrict__ save,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, const float* __restrict__ sums) {
+  ChanWalk w(C);
+  if (!w.active) return;
+  const int c = w.c;
   const float invn = 1.f / (float)npix;
-  long long total = npix * CC;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    long long p = i / CC;
-    int c = (int)(i - p * CC) << 3;
+  float a[8], b[8], mean[8], istd[8], m1[8], m2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    mean[q] = save[c + q]; istd[q] = save[C + c + q];
+    a[q] = gamma[c + q] * istd[q]; b[q] = beta[c + q];
+    m1[q] = sums[c + q] * invn; m2[q] = sums[C + c + q] * invn;
+  }
+#pragma unroll 2
+  for (long long p = w.p; p < npix; p += w.step) {
     float g[8], xv[8];
     unpack8(ld8(dy + p * lddy + c), g);
     unpack8(ld8(x + p * ldx + c), xv);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float mean = save[c + q], istd = save[C + c + q];
-      float a = gamma[c + q] * istd;
-      float xh = (xv[q] - mean) * istd;
-      float pre = (xv[q] - mean) * a + beta[c + q];
-      float gg = (!relu || pre > 0.f) ? g[q] : 0.f;
-      g[q] = a * (gg - sums[c + q] * invn - xh * sums[C + c + q] * invn);
+      float d = xv[q] - mean[q];
+      float gg = (!relu || d * a[q] + b[q] > 0.f) ? g[q] : 0.f;
+      g[q] = a[q] * (gg - m1[q] - d * istd[q] * m2[q]);
     }
     st8(dx + p * lddx + c, pack8(g));
   }
 }
 
 // partial rows [nrows][2][C] -> final sums [2][C] (read by the apply pass) and the parameter gradients
-__global__ void bn_bwd_finish_kernel(const float* __restrict__ part, int nrows, int C, float* __restrict__ fin,
-                                     float* dgamma, float* dbeta, int accumulate) {
-  __shared__ float sh[2][8][32];
+__global__ __launch_bounds__(ROWRED_THREADS) void bn_bwd_finish_kernel(const float* __restrict__ part, int nrows,
+                                                                       int C, float* __restrict__ fin, float* dgamma,
+                                                                       float* dbeta, int accumulate) {
+  __shared__ float sh[2][32][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
   float s0, s1;
   reduce_rows_2c(part, nrows, C, c, ty, s0, s1, sh);
@@ -355,7 +401,7 @@ __global__ void bn_bwd_finish_kernel(const float* __restrict__ part, int nrows, 
   }
 }
 
-#define BN_BWD_MAX_ROWS 256
+#define BN_BWD_MAX_ROWS 1024
 // scratch: fp32 [(BN_BWD_MAX_ROWS + 1) * 2 * C] (need not be zeroed).  dgamma/dbeta may be null.
 extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
                                 long long npix, int C, const float* save, const float* gamma, const float* beta,
@@ -365,15 +411,14 @@ extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, l
   CHECK_VIEW("ried_bn_backward", x, ldx, C);
   CHECK_VIEW("ried_bn_backward", dx, lddx, C);
   RIED_CHECK_ARG(save && gamma && beta && scratch && npix > 0, "ried_bn_backward: bad arguments");
-  RIED_CHECK_ARG(C <= 4096, "ried_bn_backward: C too large");
-  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, BN_BWD_MAX_ROWS);
-  if (grid * EW_THREADS < C / 8) grid = ceil_div(C / 8, EW_THREADS);
+  RIED_CHECK_ARG(C <= 8 * EW_THREADS, "ried_bn_backward: C too large");
+  int grid = chan_grid(npix, C, 4, BN_BWD_MAX_ROWS);
   float* fin = scratch + (long long)BN_BWD_MAX_ROWS * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), 2 * C * sizeof(float), stream,
-                     (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, scratch);
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, stream, scratch, grid, C, fin,
-                     (dgamma && dbeta) ? dgamma : nullptr, dbeta, accumulate);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS)), dim3(EW_THREADS), 0, stream,
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)dy, lddy,
+                     (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, scratch);
+  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(ceil_div(C, 32)), dim3(ROWRED_THREADS), 0, stream, scratch, grid, C,
+                     fin, (dgamma && dbeta) ? dgamma : nullptr, dbeta, accumulate);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chan_grid(npix, C, 2, 8192)), dim3(EW_THREADS), 0, stream,
                      (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (bf16_t*)dx, lddx, npix, C, save, gamma, beta,
                      relu, fin);
   RIED_CHECK_LAUNCH("ried_bn_backward");

@@ -14,6 +14,8 @@ VGG16 tap extractor of src/loss.py:69-87.
 """
 from __future__ import annotations
 
+import os
+
 from typing import Dict, List, Optional, Tuple
 
 import torch
@@ -241,7 +243,8 @@ class Slot:
         return (self.n1 - self.n0, v.H, v.W, self.C)
 
 
-def _splitk(blocks: int, kpix: int, target: int = 768) -> int:
+def _splitk(blocks: int, kpix: int, target: int = 0) -> int:
+    target = target or int(os.environ.get("RIED_SPLITK_TARGET", "384"))
     s = max(1, min((target + blocks - 1) // blocks, (kpix + 127) // 128))
     return min(s, 512)
 
