@@ -38,11 +38,18 @@ int ried_device_cus(void);
  *   receives one partial (sum, sum of squares) row of the fp32 results per pixel tile, rows =
  *   ried_conv2d_stat_rows(...) (for train-mode BatchNorm; per-block rows instead of atomics, which serialise);
  *   accumulate: y += result; out_f32: y is fp32 instead of bf16; y2/ldy2: optional second, fp32 copy of the
- *   result (the perceptual-loss taps are compared in fp32) or NULL. */
+ *   result (the perceptual-loss taps are compared in fp32) or NULL.
+ *   mask/ldmask/mask_slope: optional view shaped like y; the final value (after accumulate) is multiplied by
+ *   (mask > 0 ? 1 : mask_slope): the backward of the ReLU / LeakyReLU whose output `mask` is (autograd of
+ *   src/rinet.py:139,190 and the VGG ReLUs), fused into the data gradient that produces the tensor.
+ *   stats_post: the stats rows hold column sums of the FINAL values (sum in [r][0][c]) - the bias gradient of the
+ *   layer below (src/rinet.py:137) - instead of the raw results. */
 int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W, int Cin,
                 int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
                 const float* bias, int act, float* stats, int accumulate, int out_f32, float* y2, long long ldy2,
-                ried_stream_t stream);
+                const void* mask, long long ldmask, float mask_slope, int stats_post, ried_stream_t stream);
+/* out[c] += sum over rows of stats[r][0][c] (stats: [nrows][2][C], as written by ried_conv2d) */
+int ried_stat_rows_sum(const float* stats, int nrows, int C, float* out, ried_stream_t stream);
 
 int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int Cout, int sh, int sw, int transposed);
 /* tuning hook, no counterpart in the reference: force the (Cout tile, pixel tile, LDS stages) of later ried_conv2d
@@ -103,7 +110,9 @@ long long ried_bn_backward_scratch_floats(int C);
 int ried_pool_fwd(const void* x, long long ldx, void* y, long long ldy, int nimg, int H, int W, int C, int mode,
                   ried_stream_t stream);
 int ried_pool_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int nimg,
-                  int H, int W, int C, int mode, ried_stream_t stream); /* dx += */
+                  int H, int W, int C, int mode, int accumulate, int relu_mask, ried_stream_t stream);
+/* ried_pool_bwd: dx (+)= pooled gradient (accumulate != 0 adds onto dx; max modes may overwrite instead);
+ * relu_mask (max modes): the result is zeroed where x <= 0, the backward of the ReLU that produced x */ /* dx += */
 /* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (src/rinet.py:266,361) */
 int ried_upsample2x_fwd(const void* x, long long ldx, void* y, long long ldy, int nimg, int H, int W, int C,
                         ried_stream_t stream);

@@ -469,7 +469,7 @@ __global__ void pool_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, bf1
 // row-major scan order.  dx is accumulated (+=); one thread owns one INPUT pixel chunk, so no atomics.
 __global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, long long ldx, const bf16_t* __restrict__ dy,
                                    long long lddy, bf16_t* __restrict__ dx, long long lddx, int nimg, int H, int W,
-                                   int Ho, int Wo, int C, int mode) {
+                                   int Ho, int Wo, int C, int mode, int accumulate, int relu_mask) {
   const int CC = C >> 3;
   const int k = mode == 1 ? 2 : 3, s = 2, pad = mode == 1 ? 0 : 1;
   long long total = (long long)nimg * H * W * CC;
@@ -481,7 +481,11 @@ __global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, long long ldx, 
     int hy = (int)(t % H);
     int n = (int)(t / H);
     float g[8];
-    unpack8(ld8(dx + p * lddx + c), g);
+    if (accumulate) unpack8(ld8(dx + p * lddx + c), g);
+    else {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g[q] = 0.f;
+    }
     float me[8];
     unpack8(ld8(x + p * ldx + c), me);
     // output windows that contain (hy, wx)
@@ -512,6 +516,10 @@ __global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, long long ldx, 
 #pragma unroll
         for (int q = 0; q < 8; ++q) g[q] += win[q] ? d[q] : 0.f;
       }
+    if (relu_mask) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g[q] = me[q] > 0.f ? g[q] : 0.f;
+    }
     st8(dx + p * lddx + c, pack8(g));
   }
 }
@@ -566,8 +574,10 @@ extern "C" int ried_pool_fwd(const void* x, long long ldx, void* y, long long ld
 
 // dx += pool backward of dy.  x is the forward input (max modes only).
 extern "C" int ried_pool_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
-                             int nimg, int H, int W, int C, int mode, hipStream_t stream) {
+                             int nimg, int H, int W, int C, int mode, int accumulate, int relu_mask,
+                             hipStream_t stream) {
   CHECK_VIEW("ried_pool_bwd", dy, lddy, C);
+  RIED_CHECK_ARG(mode != 2 || (accumulate && !relu_mask), "ried_pool_bwd: the average mode only accumulates");
   CHECK_VIEW("ried_pool_bwd", dx, lddx, C);
   RIED_CHECK_ARG(mode >= 0 && mode <= 2 && nimg > 0 && H > 0 && W > 0, "ried_pool_bwd: bad arguments");
   int grid = ew_grid((long long)nimg * H * W * (C / 8), EW_THREADS);
@@ -579,7 +589,7 @@ extern "C" int ried_pool_bwd(const void* x, long long ldx, const void* dy, long 
     int Ho = mode == 0 ? (H + 2 - 3) / 2 + 1 : H / 2;
     int Wo = mode == 0 ? (W + 2 - 3) / 2 + 1 : W / 2;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx,
-                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, nimg, H, W, Ho, Wo, C, mode);
+                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, nimg, H, W, Ho, Wo, C, mode, accumulate, relu_mask);
   }
   RIED_CHECK_LAUNCH("ried_pool_bwd");
   return RIED_OK;
@@ -772,6 +782,33 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, int nrows, 
     for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x & 31];
     out[c] += t;
   }
+}
+
+__global__ __launch_bounds__(ROWRED_THREADS) void stat_rows_sum_kernel(const float* __restrict__ part, int nrows,
+                                                                       int C, float* __restrict__ out) {
+  __shared__ float sh[32][32];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
+  float a = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int r = ty; r < nrows; r += 32) a += part[(long long)r * 2 * C + c];
+  }
+  sh[ty][threadIdx.x & 31] = a;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) t += sh[k][threadIdx.x & 31];
+    out[c] += t;
+  }
+}
+// out[c] += sum_r stats[r][0][c]; stats: [nrows][2][C] partial rows written by a conv epilogue
+extern "C" int ried_stat_rows_sum(const float* stats, int nrows, int C, float* out, hipStream_t stream) {
+  RIED_CHECK_ARG(stats && out && nrows > 0 && C > 0, "ried_stat_rows_sum: bad arguments");
+  hipLaunchKernelGGL(stat_rows_sum_kernel, dim3(ceil_div(C, 32)), dim3(ROWRED_THREADS), 0, stream, stats, nrows, C,
+                     out);
+  RIED_CHECK_LAUNCH("ried_stat_rows_sum");
+  return RIED_OK;
 }
 
 #define COLSUM_MAX_ROWS 256

@@ -49,6 +49,10 @@ struct GemmEpilogue {
   float alpha;
   float* out2;             // optional second copy of the result in fp32 (same row mapping), or null
   long long ldc2;
+  const bf16_t* mask;      // optional: final value *= (mask[row][m] > 0 ? 1 : mask_slope)  (activation backward
+  long long ld_mask;       // fused into the data gradient that produces the tensor); applied after accumulate
+  float mask_slope;
+  int stats_post;          // stats = column sums of the final values (bias gradient) instead of the raw results
   int phase_mode, Wo_full, HoWo_full, Hq, Wq, sh, sw;   // logical row -> physical pixel
 };
 
@@ -289,7 +293,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
       float v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] * E.alpha;
-      if (E.stats) {
+      if (E.stats && !E.stats_post) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { ssum[i][q] += v[q]; ssq[i][q] += v[q] * v[q]; }
       }
@@ -313,21 +317,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
       }
       if (E.out2) *reinterpret_cast<f32x4*>(E.out2 + orow * E.ldc2 + m) = f32x4{v[0], v[1], v[2], v[3]};
       long long off = obase + orow * E.ldc + m;
-      if (E.out_f32) {
-        float* op = (float*)outb + off;
-        if (E.accumulate) {
-          f32x4 o = *reinterpret_cast<f32x4*>(op);
+      if (E.accumulate) {
+        if (E.out_f32) {
+          f32x4 o = *reinterpret_cast<const f32x4*>((const float*)outb + off);
           v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
-        }
-        *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-      } else {
-        bf16_t* op = (bf16_t*)outb + off;
-        if (E.accumulate) {
-          u32x2 o = *reinterpret_cast<u32x2*>(op);
+        } else {
+          u32x2 o = *reinterpret_cast<const u32x2*>((const bf16_t*)outb + off);
           v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
         }
-        *reinterpret_cast<u32x2*>(op) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
       }
+      if (E.mask) {
+        u32x2 mk = *reinterpret_cast<const u32x2*>(E.mask + orow * E.ld_mask + m);
+        v[0] *= bflo(mk[0]) > 0.f ? 1.f : E.mask_slope; v[1] *= bfhi(mk[0]) > 0.f ? 1.f : E.mask_slope;
+        v[2] *= bflo(mk[1]) > 0.f ? 1.f : E.mask_slope; v[3] *= bfhi(mk[1]) > 0.f ? 1.f : E.mask_slope;
+      }
+      if (E.stats && E.stats_post) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ssum[i][q] += v[q]; ssq[i][q] += v[q] * v[q]; }
+      }
+      if (E.out_f32) *reinterpret_cast<f32x4*>((float*)outb + off) = f32x4{v[0], v[1], v[2], v[3]};
+      else *reinterpret_cast<u32x2*>((bf16_t*)outb + off) = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
     }
   }
   if (E.stats) {
@@ -700,7 +709,8 @@ static void default_epilogue(GemmEpilogue& E) {
 extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
                            int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                            int transposed, const float* bias, int act, float* stats, int accumulate, int out_f32,
-                           float* y2, long long ldy2, hipStream_t stream) {
+                           float* y2, long long ldy2, const void* mask, long long ldmask, float mask_slope,
+                           int stats_post, hipStream_t stream) {
   RIED_CHECK_ARG(x && w && y, "ried_conv2d: null pointer");
   RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
   RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
@@ -741,6 +751,8 @@ extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y,
   P.E.accumulate = accumulate;
   RIED_CHECK_ARG(!y2 || (ldy2 % 4 == 0 && ldy2 >= Cout && ((uintptr_t)y2 % 16) == 0), "ried_conv2d: bad y2 view");
   P.E.out2 = y2; P.E.ldc2 = ldy2;
+  RIED_CHECK_ARG(!mask || (ldmask % 4 == 0 && ldmask >= Cout && ((uintptr_t)mask % 8) == 0), "ried_conv2d: bad mask view");
+  P.E.mask = (const bf16_t*)mask; P.E.ld_mask = ldmask; P.E.mask_slope = mask_slope; P.E.stats_post = stats_post;
   long long a_bytes = (long long)Cout * kh * kw * Cin * 2;
   long long b_bytes = (((long long)nimg * H * W - 1) * ldx + Cin) * 2;
   RIED_CHECK_ARG(a_bytes < (long long)GLDS_OOB - (1 << 28) && b_bytes < (long long)GLDS_OOB,

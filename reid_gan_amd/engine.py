@@ -97,6 +97,11 @@ class Act:
 
     def __init__(self, v: View, g: Optional[View]):
         self.v, self.g = v, g
+        # Activation backward fused into the producer of g: the layer whose output this is sets fuse_slope (its
+        # ReLU / LeakyReLU slope); the layer that writes g sets `fused` (its stats rows hold the bias gradient's
+        # partial sums) and from then on g holds the gradient w.r.t. the PRE-activation values.
+        self.fuse_slope: Optional[float] = None
+        self.fused: Optional["_Fused"] = None
 
     def slice(self, c0, c1) -> "Act":
         return Act(self.v.slice(c0, c1), None if self.g is None else self.g.slice(c0, c1))
@@ -119,6 +124,7 @@ class Ctx:
         self.tmp_elems = 0
         self.f32_elems = 0            # shared fp32 scratch (BN backward partial rows, column sums)
         self._stats_req: List[Tuple[object, str, int]] = []
+        self.chain = False                 # True: no activation gradient has two writers, nothing needs zeroing
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
         self.wreds = ops.JobTable(11)      # every weight-gradient slab reduction: one launch (end_backward)
         self._wred_slab: List[Tuple[int, int]] = []      # (job, slab offset) patched once the arena exists
@@ -197,11 +203,21 @@ class Ctx:
         self.pack_all()          # BN partial-sum rows need no clearing: the conv epilogues overwrite them
 
     def zero_backward(self):
-        self.grad_arena.zero_()
+        if not self.chain:       # a chain plan overwrites every gradient buffer before reading it
+            self.grad_arena.zero_()
 
     def end_backward(self):
         """Reduce the weight-gradient slabs of every layer into the master gradients (one launch)."""
         ops.wgrad_reduce_jobs(self.wreds)
+
+
+class _Fused:
+    """Stats rows a data-gradient epilogue fills with the column sums of the masked gradient it writes."""
+
+    def __init__(self, ctx: "Ctx", nimg, H, W, C, sh, sw):
+        self.rows = ops.conv2d_stat_rows(nimg, H, W, C, sh, sw, True)
+        self.C = C
+        ctx.stats(self, "stats", self.rows * 2 * C)
 
 
 # Deferred gradient pointers: Views handed out before Ctx.finalize() hold offsets.  Slices taken before
@@ -308,10 +324,10 @@ class ConvCore:
         ops.conv2d(self.xin.v, self.wp, y, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
                    transposed=self.deconv, **kw)
 
-    def dgrad(self, dy: View, dx: View):
-        """dx += data gradient of dy (d loss / d conv output)."""
+    def dgrad(self, dy: View, dx: View, accumulate=True, **kw):
+        """dx (+)= data gradient of dy (d loss / d conv output); kw: mask / mask_slope / stats / stats_post."""
         ops.conv2d(dy, self.wpt, dx, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
-                   transposed=not self.deconv, accumulate=True)
+                   transposed=not self.deconv, accumulate=accumulate, **kw)
 
     def wgrad(self, dy: View, x: Optional[View] = None):
         """Split-K partial weight gradients into this layer's slab; Ctx.end_backward() reduces all layers."""
@@ -676,6 +692,10 @@ class SNConv:
             ctx.need_f32(ops.colsum_scratch_floats(cout))
             if first:
                 ctx.need_f32(ops.conv_c1_wgrad_scratch_floats(cout))
+            out.act.fuse_slope = 0.2          # whoever writes out.g may apply this layer's LeakyReLU backward
+            if not first and xin.act.fuse_slope is not None:
+                _, H, W, _ = xin.shape
+                xin.act.fused = _Fused(ctx, N, H, W, cin, stride, stride)
         self.x_img: Optional[torch.Tensor] = None
 
     def compute_sigma(self):
@@ -698,10 +718,18 @@ class SNConv:
         ctx, st, p = self.ctx, self.ctx.st, self.prefix
         out = self.out.images(n0, n1)
         N, Ho, Wo, C = out.shape
-        dpre = ctx.tmp_view(N, Ho, Wo, C)
-        ops.ew(ops.EW_ACTBWD, out.g, dpre, y=out.v, slope=0.2)
+        fz = self.out.act.fused
+        if fz is not None:       # out.g already holds the pre-activation gradient; its column sums are in fz.stats
+            dpre = out.g
+            if wgrad:
+                assert N == self.out.shape[0], "bias column sums cover the whole batch"
+                ops.stat_rows_sum(fz.stats, fz.rows, C, st.g[p + ".bias"])
+        else:
+            dpre = ctx.tmp_view(N, Ho, Wo, C)
+            ops.ew(ops.EW_ACTBWD, out.g, dpre, y=out.v, slope=0.2)
+            if wgrad:
+                ops.colsum(dpre, st.g[p + ".bias"], ctx.f32)
         if wgrad:
-            ops.colsum(dpre, st.g[p + ".bias"], ctx.f32)
             if self.first:
                 self.dwsn.zero_()
                 ops.conv_c1_wgrad(self.x_img[n0:n1], dpre, self.stride, self.dwsn, ctx.f32)
@@ -711,7 +739,13 @@ class SNConv:
             if dimg is not None:
                 ops.conv_c1_dgrad(dpre, st.p[p + ".weight_orig"], dimg, sigma=self.sigma, accumulate=True)
         else:
-            self.core.dgrad(dpre, self.core.xin.images(n0, n1).g)
+            xin = self.core.xin.images(n0, n1)
+            xf = self.core.xin.act.fused
+            if xf is not None:
+                self.core.dgrad(dpre, xin.g, accumulate=False, mask=xin.v, mask_slope=self.core.xin.act.fuse_slope,
+                                stats=xf.stats if wgrad else None, stats_post=True)
+            else:
+                self.core.dgrad(dpre, xin.g, accumulate=False)
 
     def finish_wgrad(self):
         """After Ctx.end_backward(): gradient of W/sigma (in dwsn) -> gradient of weight_orig."""
@@ -755,6 +789,8 @@ class Attn:
             self.slab_off = ctx.alloc_slab(self.splitk * self.cq * C)
             ctx.add_wgrad_reduce(self.slab_off, self.dw, self.splitk, 1, self.cq, C, 1, C, 1)
             ctx.need_f32(ops.colsum_scratch_floats(self.cq))
+            if xin.act.fuse_slope is not None:
+                xin.act.fused = _Fused(ctx, N, H, W, C, 1, 1)
 
     def _names(self):
         p = self.prefix
@@ -780,7 +816,7 @@ class Attn:
         out, xin, qkv = self.out.images(n0, n1), self.xin.images(n0, n1), self.qkv.images(n0, n1)
         O, dO = self.O.images(n0, n1), self.dO.images(n0, n1)
         gamma = st.p[self.prefix + ".gamma"]
-        ops.ew(ops.EW_ADD, out.g, xin.g)                                    # residual path
+        ops.ew(ops.EW_COPY, out.g, xin.g)                                   # residual path (first writer of xin.g)
         if wgrad:
             ops.dot(out.g, O, 1.0, st.g[self.prefix + ".gamma"])
         ops.ew(ops.EW_SCALE, out.g, dO, s=gamma)
@@ -803,7 +839,12 @@ class Attn:
         if wgrad:             # bias and weight gradients land directly in the state's (zeroed) gradient buffer
             ops.colsum(qkv.g, self.db, self.ctx.f32)
             ops.conv2d_wgrad(xin.v, qkv.g, 1, 1, 1, 1, 0, 0, self.ctx.slab_at(self.slab_off), self.splitk)
-        ops.conv2d(qkv.g, self.wpt, xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True)
+        xf = self.xin.act.fused
+        if xf is not None:
+            ops.conv2d(qkv.g, self.wpt, xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True, mask=xin.v,
+                       mask_slope=self.xin.act.fuse_slope, stats=xf.stats if wgrad else None, stats_post=True)
+        else:
+            ops.conv2d(qkv.g, self.wpt, xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True)
 
 
 class Discriminator:
@@ -832,6 +873,7 @@ class Discriminator:
             Attn(ctx, p + "5", 512, a4, a5),
             SNConv(ctx, p + "6.conv2d", 512, 512, 2, a5, a6),
         ]
+        ctx.chain = True         # every gradient buffer has exactly one first writer that overwrites it
         ctx.finalize()
         self.out_features = 512 * (H // 16) * (W // 16)
 
@@ -898,12 +940,14 @@ class Vgg:
         cur = Slot(ctx.act(N, H, W, 64))
         self.a0 = cur
         idx, cin, h, w = 2, 64, H, W
+        cur_is_conv, cur_is_tap = True, False          # what produced `cur`; whether the loss seeds its gradient
         for v in VGG_CFG[1:]:
             if v == "M":
                 nxt = Slot(ctx.act(N, h // 2, w // 2, cin))
-                self.layers.append(("pool", Pool(ctx, ops.POOL_MAX2S2, cur, nxt)))
+                self.layers.append(("pool", Pool(ctx, ops.POOL_MAX2S2, cur, nxt), cur_is_tap))
                 h, w = h // 2, w // 2
                 idx += 1
+                cur_is_conv, cur_is_tap = False, False
             else:
                 nxt = Slot(ctx.act(N, h, w, v))
                 core = ConvCore(ctx, f"{idx}.weight", cin, v, 3, 1, 1, False, cur, True, need_wgrad=False)
@@ -917,12 +961,12 @@ class Vgg:
                 if idx - 1 in VGG_TAPS:        # taps are also kept in fp32: the loss is a small difference
                     tap32 = torch.empty(N, h, w, v, dtype=F32, device=dev)
                     self.taps.append((nxt, tap32))
-                self.layers.append(("conv", core, weights[f"{idx - 2}.bias"].to(dev, F32).contiguous(), nxt, tap32))
-                if grads:
-                    ctx.need_tmp(B * h * w * v)
+                self.layers.append(("conv", core, weights[f"{idx - 2}.bias"].to(dev, F32).contiguous(), nxt, tap32,
+                                    cur_is_conv, cur_is_tap))
+                cur_is_conv, cur_is_tap = True, tap32 is not None
             cur = nxt
-        if grads:
-            ctx.need_tmp(B * H * W * 64)
+        assert self.layers[-1][0] == "conv" and cur_is_tap      # the deepest tensor is a tap without a consumer
+        ctx.chain = True             # every gradient buffer is overwritten by its first writer: nothing to zero
         ctx.finalize()
         torch.cuda.synchronize()
 
@@ -933,7 +977,7 @@ class Vgg:
             if l[0] == "pool":
                 l[1].forward()
             else:
-                _, core, bias, out, tap32 = l
+                _, core, bias, out, tap32 = l[:5]
                 core.conv(out.v, bias=bias, act=1, y2=tap32)
 
     def loss_and_seed(self, loss: torch.Tensor, weight: float):
@@ -950,19 +994,22 @@ class Vgg:
 
     def backward(self, dimg: torch.Tensor):
         """dimg: fp32 (B,1,H,W), += d loss / d prediction image."""
-        B, ctx = self.B, self.ctx
+        B = self.B
+        # Every gradient buffer holds the gradient w.r.t. the PRE-ReLU values: the ReLU backward is applied by
+        # whatever writes the buffer (data-gradient epilogue or pooling backward).  The deepest tap has no
+        # consumer, so its seed is masked here.
+        o = self.layers[-1][3].images(0, B)
+        ops.ew(ops.EW_ACTBWD, o.g, o.g, y=o.v, slope=0.0)
         for l in reversed(self.layers):
             if l[0] == "pool":
-                p = l[1]
-                ops.pool_bwd(p.xin.images(0, B).v, p.out.images(0, B).g, p.xin.images(0, B).g, p.mode)
+                p, seeded = l[1], l[2]
+                xi = p.xin.images(0, B)
+                ops.pool_bwd(xi.v, p.out.images(0, B).g, xi.g, p.mode, accumulate=seeded, relu_mask=True)
             else:
-                _, core, bias, out, _t = l
-                o = out.images(0, B)
-                N, Ho, Wo, C = o.shape
-                dpre = ctx.tmp_view(N, Ho, Wo, C)
-                ops.ew(ops.EW_ACTBWD, o.g, dpre, y=o.v, slope=0.0)
-                core.dgrad(dpre, core.xin.images(0, B).g)
-        o = self.a0.images(0, B)
-        dpre = ctx.tmp_view(B, self.H, self.W, 64)
-        ops.ew(ops.EW_ACTBWD, o.g, dpre, y=o.v, slope=0.0)
-        ops.conv_c1_dgrad(dpre, self.w0, dimg, scale=1.0 / 4096.0, accumulate=True)
+                _, core, bias, out, _t, in_is_conv, in_is_tap = l
+                xi = core.xin.images(0, B)
+                if in_is_conv:
+                    core.dgrad(out.images(0, B).g, xi.g, accumulate=in_is_tap, mask=xi.v, mask_slope=0.0)
+                else:
+                    core.dgrad(out.images(0, B).g, xi.g, accumulate=False)
+        ops.conv_c1_dgrad(self.a0.images(0, B).g, self.w0, dimg, scale=1.0 / 4096.0, accumulate=True)

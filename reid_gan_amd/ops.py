@@ -68,10 +68,19 @@ def new_view(N: int, H: int, W: int, C: int, device="cuda", zero: bool = False) 
 
 # --------------------------------------------------------------------------- GEMM family
 def conv2d(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed=False, bias=None, act=0,
-           stats=None, accumulate=False, out_f32=False, y2: Optional[torch.Tensor] = None):
+           stats=None, accumulate=False, out_f32=False, y2: Optional[torch.Tensor] = None,
+           mask: Optional[View] = None, mask_slope=0.0, stats_post=False):
+    """mask: view shaped like y; the stored value is multiplied by (mask > 0 ? 1 : mask_slope) (activation backward
+    fused into a data gradient); stats_post: stats rows receive column sums of the stored values."""
     lib.ried_conv2d(x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C, kh, kw, sh, sw, ph, pw,
                     int(transposed), _p(bias), act, _p(stats), int(accumulate), int(out_f32), _p(y2), y.C,
+                    None if mask is None else mask.ptr, 0 if mask is None else mask.ld, mask_slope, int(stats_post),
                     _stream())
+
+
+def stat_rows_sum(stats: torch.Tensor, nrows: int, C: int, out: torch.Tensor):
+    """out[c] += sum over the rows of stats[r][0][c]."""
+    lib.ried_stat_rows_sum(_p(stats), nrows, C, _p(out), _stream())
 
 
 def conv2d_wgrad(g: View, p: View, kh, kw, sh, sw, ph, pw, slab, splitk: int):
@@ -178,9 +187,9 @@ def pool_fwd(x: View, y: View, mode: int):
     lib.ried_pool_fwd(x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, mode, _stream())
 
 
-def pool_bwd(x: Optional[View], dy: View, dx: View, mode: int):
+def pool_bwd(x: Optional[View], dy: View, dx: View, mode: int, accumulate=True, relu_mask=False):
     lib.ried_pool_bwd(None if x is None else x.ptr, 0 if x is None else x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, dx.N,
-                      dx.H, dx.W, dx.C, mode, _stream())
+                      dx.H, dx.W, dx.C, mode, int(accumulate), int(relu_mask), _stream())
 
 
 def upsample2x_fwd(x: View, y: View):

@@ -12,7 +12,7 @@ def test_header_parses_and_names_entry_points():
         assert name in protos, name
     assert len(protos) >= 35
     ret, args = protos["ried_conv2d"]
-    assert ret == "int" and len(args) == 27 and args[-1][0] == "ried_stream_t"
+    assert ret == "int" and len(args) == 31 and args[-1][0] == "ried_stream_t"
 
 
 def test_library_exports_every_declared_symbol():
@@ -28,7 +28,7 @@ def test_argument_validation_needs_no_gpu():
     """Bad arguments are rejected before any launch, with a message."""
     _lib.lib.load()
     try:
-        _lib.lib.ried_conv2d(None, 8, None, None, 8, 1, 4, 4, 8, 4, 4, 8, 3, 3, 1, 1, 1, 1, 0, None, 0, None, 0, 0, None, 0, None)
+        _lib.lib.ried_conv2d(None, 8, None, None, 8, 1, 4, 4, 8, 4, 4, 8, 3, 3, 1, 1, 1, 1, 0, None, 0, None, 0, 0, None, 0, None, 0, 0.0, 0, None)
     except RuntimeError as e:
         assert "null pointer" in str(e)
     else:

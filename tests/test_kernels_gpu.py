@@ -164,6 +164,43 @@ def test_deconv_wgrad():
     close(out.cpu(), ref, 3e-3, "dW")
 
 
+@pytest.mark.parametrize("cin,cout,s,slope,acc", [(128, 64, 2, 0.2, False), (64, 72, 1, 0.0, True),
+                                                  (512, 256, 2, 0.2, True)])
+def test_conv2d_fused_activation_backward_and_bias_sums(cin, cout, s, slope, acc):
+    """Data gradient of a strided 3x3 conv with the (Leaky)ReLU backward of the tensor it produces and the column
+    sums of the masked result (the bias gradient of the layer below) fused into the epilogue."""
+    N, H = 3, 8
+    g = r(N, cin, H, H, seed=41)                                   # gradient w.r.t. the conv output
+    w = r(cin, cout, 3, 3, seed=42, scale=(cin * 9) ** -0.5)       # the conv's weight is (cin_out=cin, cout_in=cout)
+    Ho = H * s
+    dx = F.conv_transpose2d(g, w, None, s, 1, output_padding=s - 1)
+    yact = r(N, cout, Ho, Ho, seed=43)                             # forward output of the layer below
+    old = r(N, cout, Ho, Ho, seed=44)
+    ref = (dx + (old if acc else 0)) * torch.where(yact > 0, 1.0, slope)
+    yv = to_view(old)
+    rows = ops.conv2d_stat_rows(N, Ho, Ho, cout, s, s, True)
+    stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
+    ops.conv2d(to_view(g), pack(w.permute(1, 0, 2, 3)), yv, 3, 3, s, s, 1, 1, transposed=True, accumulate=acc,
+               mask=to_view(yact), mask_slope=slope, stats=stats, stats_post=True)
+    close(from_view(yv), ref, what="masked dgrad")
+    bias = torch.zeros(cout, device=DEV)
+    ops.stat_rows_sum(stats, rows, cout, bias)
+    close(bias.cpu(), ref.sum((0, 2, 3)), 2e-2, "bias gradient")
+
+
+def test_maxpool_bwd_overwrite_and_relu_mask():
+    x = r(2, 16, 8, 8, seed=51)
+    xr = x.clone().requires_grad_(True)
+    y = F.max_pool2d(torch.relu(xr), 2, 2)
+    gy = r(*y.shape, seed=52)
+    (gx,) = torch.autograd.grad(y, xr, gy)                       # ReLU backward included
+    xpost = torch.relu(x)
+    dxv = to_view(torch.full_like(x, 7.0))                        # garbage that must be overwritten
+    ops.pool_bwd(to_view(xpost), to_view(gy), dxv, ops.POOL_MAX2S2, accumulate=False, relu_mask=True)
+    # where several window elements tie at 0 after the ReLU the mask zeroes them anyway
+    close(from_view(dxv), gx, what="maxpool+relu backward")
+
+
 def test_job_table_pack_and_reduce_match_single_calls():
     """One launch over a job table = the per-layer calls, bit for bit (same arithmetic per element)."""
     g = torch.Generator().manual_seed(5)

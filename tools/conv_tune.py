@@ -8,10 +8,10 @@ from reid_gan_amd._lib import lib
 # (N, H, W, Cin, Cout, kh, kw, stride, transposed, count per step)
 SHAPES = [l.split() for l in open(sys.argv[1]).read().strip().splitlines()] if len(sys.argv) > 1 else None
 CONFIGS = [(128, 128, 2), (128, 128, 3), (128, 64, 2), (128, 64, 3), (128, 64, 4), (64, 128, 2), (64, 128, 3),
-           (64, 64, 2), (64, 64, 4)]
+           (64, 128, 4), (64, 64, 2), (64, 64, 3), (64, 64, 4)]
 
 
-def run(N, H, W, Cin, Cout, kh, kw, s, tr, reps=10):
+def run(N, H, W, Cin, Cout, kh, kw, s, tr, reps=20):
     ph, pw = (kh - 1) // 2, (kw - 1) // 2
     if kh == 4:
         ph = pw = 1
@@ -32,10 +32,14 @@ def run(N, H, W, Cin, Cout, kh, kw, s, tr, reps=10):
         try:
             f = lambda: ops.conv2d(x, w, y, kh, kw, s, s, ph, pw, transposed=bool(tr))
             f(); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()           # graph replay: launch overhead off the clock
+            with torch.cuda.graph(g):
+                for _ in range(reps):
+                    f()
+            g.replay(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(reps):
-                f()
+            g.replay()
             e1.record(); torch.cuda.synchronize()
             out[cfg] = e0.elapsed_time(e1) * 1e3 / reps
         except RuntimeError as e:
