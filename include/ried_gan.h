@@ -62,6 +62,7 @@ int ried_conv2d_force_tile(int bm, int bn, int nst);
 int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg, int H, int W, const void* p, long long ldp,
                       int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw, float* slab, int splitk,
                       ried_stream_t stream);
+int ried_conv2d_wgrad_tiles(int Cg, int Cp); /* blocks per (tap, split) of ried_conv2d_wgrad: for choosing splitk */
 /* out[tap*st + p*sp + g*sg] (+)= scale * sum over splits: scatters into the (Cout,Cin,kh,kw) or (Cin,Cout,kh,kw)
  * fp32 master gradient. */
 int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp, int Cg, float* out, long long st, long long sp,

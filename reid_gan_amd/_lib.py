@@ -47,7 +47,7 @@ def _ctype_of(t: str):
     return _CTYPES[t]
 
 
-_VALUE_SUFFIXES = ("_rows", "_floats", "_version", "_cus")
+_VALUE_SUFFIXES = ("_rows", "_floats", "_version", "_cus", "_tiles")
 
 
 class _Lib:

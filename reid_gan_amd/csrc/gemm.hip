@@ -67,17 +67,25 @@ struct GemmParams {
   unsigned A_bytes, B_bytes;   // extent of the operands in bytes (buffer descriptors of the LDS-DMA kernel)
 };
 
-constexpr int BK = 32;
+constexpr int BK = 64;                            // k per stage: two MFMA k-slices of 32
 constexpr int LDK_PAD = 8;
 
 template <int R>
 struct TileGeom {
-  static constexpr int NCH = R / 64;              // 16-byte chunks per thread per tile
-  static constexpr int LDK = BK + LDK_PAD;        // [row][k] image: elements per row
-  static constexpr int LDR = R + 8;               // [k][row] image: elements per k
+  static constexpr int NCH = R * (BK / 8) / 256;  // 16-byte chunks per thread per tile
+  static constexpr int LDK = BK + LDK_PAD;        // [row][k] image: elements per row (144-byte rows: the 16 rows
+                                                  // of a ds_read_b128 group fall on 16 different 16-byte bank slots)
+  static constexpr int LDR = R;                   // [k][row] image: elements per k, XOR-swizzled (tr_swz)
   static constexpr int ELEMS = (R * LDK > BK * LDR) ? R * LDK : BK * LDR;
   static constexpr int CPR = R / 8;               // chunks per k row (TR)
   static constexpr int KR = 256 / CPR;            // k rows per pass (TR)
+  // [k][row] image: the 32-byte slot (16 rows of the operand) s of k-row k is stored in slot s ^ h(k), so that the
+  // 8 k-rows one 32-lane half of a ds_read_b64_tr_b16 touches (k = 8g + q; g = 0..1, q = 0..3, same columns) fall
+  // on 8 different 32-byte slots of the 256-byte bank window.  Returns the element offset to XOR with.
+  __device__ static __forceinline__ int tr_swz(int k) {
+    if constexpr (R >= 128) return ((((k >> 3) & 1) << 2) | (k & 3)) << 4;
+    else return ((((k >> 3) & 1) << 1) | ((k >> 1) & 1)) << 4;      // 128-byte rows: two k-rows per bank window
+  }
 };
 
 // ---------------------------------------------------------------------------
@@ -98,18 +106,18 @@ struct Loader {
                                        int pa, int pb, int r0, int s0) {
     const int t = threadIdx.x;
     if constexpr (KIND == OP_PLAIN_K) {
-      c8 = (t & 3) * 8;
+      c8 = (t & 7) * 8;
 #pragma unroll
       for (int i = 0; i < G::NCH; ++i) {
-        int rowg = row0 + (t >> 2) + 64 * i;
+        int rowg = row0 + (t >> 3) + 32 * i;
         valid[i] = rowg < op.rows;
         ptr[i] = op.p + batch * op.batch_stride + (long long)rowg * op.ld + c8;
       }
     } else if constexpr (KIND == OP_GATHER_K) {
-      c8 = (t & 3) * 8;
+      c8 = (t & 7) * 8;
 #pragma unroll
       for (int i = 0; i < G::NCH; ++i) {
-        int rowg = row0 + (t >> 2) + 64 * i;
+        int rowg = row0 + (t >> 3) + 32 * i;
         valid[i] = rowg < op.rows;
         int hw = op.Ho * op.Wo;
         int n = rowg / hw, rem = rowg - n * hw;
@@ -223,28 +231,30 @@ struct Loader {
     if constexpr (KIND == OP_PLAIN_K || KIND == OP_GATHER_K) {
 #pragma unroll
       for (int i = 0; i < G::NCH; ++i) {
-        int r = (t >> 2) + 64 * i;
+        int r = (t >> 3) + 32 * i;
         *reinterpret_cast<u32x4*>(lds + r * G::LDK + c8) = v[i];
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < G::NCH; ++i) *reinterpret_cast<u32x4*>(lds + kidx[i] * G::LDR + c8) = v[i];
+      for (int i = 0; i < G::NCH; ++i)
+        *reinterpret_cast<u32x4*>(lds + kidx[i] * G::LDR + (c8 ^ G::tr_swz(kidx[i]))) = v[i];
     }
   }
 };
 
-// fragment of 16 rows x 32 k for the MFMA: lane l holds row (l&15), k = 8*(l>>4) .. +7
+// fragment of 16 rows x 32 k (k-slice ks of the stage) for the MFMA: lane l holds row (l&15), k = 8*(l>>4) .. +7
 template <int KIND, int R>
-__device__ __forceinline__ bf16x8_t read_frag(const bf16_t* lds, int rowbase, int lane) {
+__device__ __forceinline__ bf16x8_t read_frag(const bf16_t* lds, int rowbase, int lane, int ks) {
   using G = TileGeom<R>;
   if constexpr (KIND == OP_PLAIN_K || KIND == OP_GATHER_K) {
-    const bf16_t* q = lds + (rowbase + (lane & 15)) * G::LDK + (lane >> 4) * 8;
+    const bf16_t* q = lds + (rowbase + (lane & 15)) * G::LDK + ks * 32 + (lane >> 4) * 8;
     return *reinterpret_cast<const bf16x8_t*>(q);
   } else {
     // [k][row] image; ds_read_b64_tr_b16 per 16-lane group: lane 4q+p supplies the address of
     // k row q, rows-of-operand 4p..4p+3; lane i receives operand row i for the 4 k rows.
     int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const bf16_t* a0 = lds + (8 * g + q) * G::LDR + rowbase + 4 * p;
+    const int k = ks * 32 + 8 * g + q;                      // tr_swz(k) == tr_swz(k + 4)
+    const bf16_t* a0 = lds + k * G::LDR + ((rowbase + 4 * p) ^ G::tr_swz(k));
     const bf16_t* a1 = a0 + 4 * G::LDR;
     typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
@@ -476,16 +486,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
       la.load(P.A, ra, koffA, kc, kt, kbeg + kc, r0, s0);
       lb.load(P.B, rb, 0, kc, kt, kbeg + kc, r0, s0);
     }
-    bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) fa[i] = read_frag<AKIND, BM>(a_cur, wm * (BM / 2) + i * 16, lane);
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[j] = read_frag<BKIND, BN>(b_cur, wn * (BN / 2) + j * 16, lane);
+      for (int i = 0; i < TM; ++i) fa[i] = read_frag<AKIND, BM>(a_cur, wm * (BM / 2) + i * 16, lane, ks);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int j = 0; j < TN; ++j) fb[j] = read_frag<BKIND, BN>(b_cur, wn * (BN / 2) + j * 16, lane, ks);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
     if (more) {
       la.store(a_nxt, ra);
       lb.store(a_nxt + GA::ELEMS, rb);
@@ -803,17 +816,20 @@ extern "C" int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg,
   P.E.out = slab; P.E.ldc = Cg; P.E.out_f32 = 1;
   P.E.tap_stride = (long long)Cp * Cg;
   P.E.batch_stride = (long long)kh * kw * Cp * Cg;      // per split
-  if (Cg <= 64 && Cp <= 64) {
-    P.tiles_m = 1;
-    dim3 grid(1, kh * kw, splitk);
-    launch<64, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
-  } else {
-    P.tiles_m = ceil_div(Cg, 128);
-    dim3 grid(P.tiles_m * ceil_div(Cp, 128), kh * kw, splitk);
-    launch<128, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
-  }
+  const int bm = Cg <= 64 ? 64 : 128, bn = Cp <= 64 ? 64 : 128;      // ried_conv2d_wgrad_tiles mirrors this
+  P.tiles_m = ceil_div(Cg, bm);
+  dim3 grid(P.tiles_m * ceil_div(Cp, bn), kh * kw, splitk);
+  if (bm == 64 && bn == 64) launch<64, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
+  else if (bm == 64) launch<64, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
+  else if (bn == 64) launch<128, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
+  else launch<128, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
   RIED_CHECK_LAUNCH("ried_conv2d_wgrad");
   return RIED_OK;
+}
+
+// output tiles (blocks per tap and split) of ried_conv2d_wgrad for Cg x Cp: for choosing splitk
+extern "C" int ried_conv2d_wgrad_tiles(int Cg, int Cp) {
+  return ceil_div(Cg, Cg <= 64 ? 64 : 128) * ceil_div(Cp, Cp <= 64 ? 64 : 128);
 }
 
 // Batched out[b][n][m] = alpha * sum_k A[b][m][k] B[b][n][k]  (+ gamma*value + resid, or accumulate).

@@ -300,9 +300,7 @@ class ConvCore:
             # weight gradient: gathered tensor g / pixel-indexed tensor p (see ried_conv2d_wgrad)
             cg, cp = (cout, cin) if deconv else (cin, cout)
             kp = N * (H * W if deconv else self.Ho * self.Wo)
-            big = not (cg <= 64 and cp <= 64)
-            tiles = ((cg + 127) // 128) * ((cp + 127) // 128) if big else 1
-            self.splitk = _splitk(tiles * taps, kp)
+            self.splitk = _splitk(ops.conv2d_wgrad_tiles(cg, cp) * taps, kp)
             self.slab_off = ctx.alloc_slab(self.splitk * taps * cin * cout)
             out = ctx.st.g[wname] if wgrad_out is None else wgrad_out
             if deconv:    # slab [taps][Cp=cin][Cg=cout] -> master (Cin,Cout,kh,kw)
@@ -785,7 +783,7 @@ class Attn:
             self.db = st.flat_grad[ob:ob + self.cq]
             ctx.add_pack(self.wcat, self.wpt, C, 1, 1, self.cq, 1, 1, 1, C)   # [C][1][1][cq] for the data gradient
             kp = N * self.n
-            self.splitk = _splitk(((C + 127) // 128) * ((self.cq + 127) // 128), kp)
+            self.splitk = _splitk(ops.conv2d_wgrad_tiles(C, self.cq), kp)
             self.slab_off = ctx.alloc_slab(self.splitk * self.cq * C)
             ctx.add_wgrad_reduce(self.slab_off, self.dw, self.splitk, 1, self.cq, C, 1, C, 1)
             ctx.need_f32(ops.colsum_scratch_floats(self.cq))

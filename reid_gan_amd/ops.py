@@ -89,6 +89,10 @@ def conv2d_wgrad(g: View, p: View, kh, kw, sh, sw, ph, pw, slab, splitk: int):
                           slab if isinstance(slab, int) else _p(slab), splitk, _stream())
 
 
+def conv2d_wgrad_tiles(Cg, Cp) -> int:
+    return lib.ried_conv2d_wgrad_tiles(Cg, Cp)
+
+
 def wgrad_reduce(slab, splitk, taps, Cp, Cg, out: torch.Tensor, st, sp, sg, scale=1.0, accumulate=False):
     lib.ried_wgrad_reduce(_p(slab), splitk, taps, Cp, Cg, _p(out), st, sp, sg, scale, int(accumulate), _stream())
 
