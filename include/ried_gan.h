@@ -68,8 +68,8 @@ int ried_conv2d_wgrad_tiles(int Cg, int Cp); /* blocks per (tap, split) of ried_
 int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp, int Cg, float* out, long long st, long long sp,
                       long long sg, float scale, int accumulate, ried_stream_t stream);
 /* Job-table forms (one launch for all layers of a network; the reference has one torch op per layer).  A job is a
- * row of 64-bit words holding pointers and integers; blockmap[b] = (job, chunk): block b handles elements
- * [2048*chunk, 2048*(chunk+1)) of its job.
+ * row of 64-bit words holding pointers and integers; blockmap[b] = (job, chunk): for pack jobs block b handles
+ * elements [2048*chunk, 2048*(chunk+1)) of its job, for reduce jobs the output row p = chunk (Cp blocks per job).
  *   pack job (13 words): src, dst, sigma|0, N, R, S, C, sn, sr, ss, sc, dst_pitch, dst_f32 - as ried_pack_weight,
  *     with dst[n*dst_pitch + (r*S+s)*C + c]; dst is fp32 instead of bf16 when dst_f32 != 0.
  *   reduce job (11 words): slab, out, splitk, split_stride, taps, Cp, Cg, st, sp, sg, accumulate - as

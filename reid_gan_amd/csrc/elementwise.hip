@@ -134,36 +134,54 @@ extern "C" int ried_pack_jobs(const long long* jobs, const int* blockmap, int nb
 #define WRED_JOB_WORDS 11
 // reduce job: slab, out, splitk, split_stride, taps, Cp, Cg, st, sp, sg, accumulate
 //   out[tap*st + p*sp + g*sg] (+)= sum_k slab[k*split_stride + (tap*Cp + p)*Cg + g]
+// blockmap[b] = (job, p): one block per output row p.  The slab is read in its own order (g fastest) and the row
+// is transposed through LDS so that masters whose row is laid out [g][tap] (st == 1, sg == taps: every conv,
+// deconv and attention weight) are written as one contiguous run; other layouts fall back to scattered stores.
+#define WRED_MAX_ROW 8192
 __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const long long* __restrict__ jobs,
                                                                 const int* __restrict__ blockmap) {
+  __shared__ float rowbuf[WRED_MAX_ROW];
   const long long* J = jobs + (long long)blockmap[2 * blockIdx.x] * WRED_JOB_WORDS;
+  const int p = blockmap[2 * blockIdx.x + 1];
   const float* slab = (const float*)J[0];
   float* out = (float*)J[1];
-  const int splitk = (int)J[2], Cp = (int)J[5], Cg = (int)J[6];
+  const int splitk = (int)J[2], taps = (int)J[4], Cp = (int)J[5], Cg = (int)J[6];
   const long long stride = J[3], st = J[7], sp = J[8], sg = J[9];
-  const long long total = J[4] * Cp * Cg;
-  const long long i0 = (long long)blockmap[2 * blockIdx.x + 1] * JOB_CHUNK + threadIdx.x;
-  constexpr int U = JOB_CHUNK / 256;
-  float acc[U];
+  const int E = taps * Cg;
+  const bool contiguous = st == 1 && sg == taps && E <= WRED_MAX_ROW;
+  constexpr int U = 4;
+  for (int e0 = threadIdx.x; e0 < E; e0 += 256 * U) {
+    float acc[U];
+    long long base[U];
 #pragma unroll
-  for (int u = 0; u < U; ++u) acc[u] = 0.f;
-  for (int k = 0; k < splitk; ++k) {            // U independent loads in flight per split
-    const float* s = slab + k * stride + i0;
+    for (int u = 0; u < U; ++u) {
+      int e = e0 + u * 256;
+      int tap = e / Cg, g = e - tap * Cg;
+      base[u] = ((long long)tap * Cp + p) * Cg + g;
+      acc[u] = 0.f;
+    }
+    for (int k = 0; k < splitk; ++k) {          // U independent loads in flight per split
+      const float* s = slab + k * stride;
 #pragma unroll
-    for (int u = 0; u < U; ++u)
-      if (i0 + u * 256 < total) acc[u] += s[u * 256];
+      for (int u = 0; u < U; ++u)
+        if (e0 + u * 256 < E) acc[u] += s[base[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int e = e0 + u * 256;
+      if (e >= E) break;
+      int tap = e / Cg, g = e - tap * Cg;
+      if (contiguous) rowbuf[g * taps + tap] = acc[u];
+      else {
+        float* o = out + tap * st + p * sp + g * sg;
+        *o = J[10] ? *o + acc[u] : acc[u];
+      }
+    }
   }
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    long long i = i0 + u * 256;
-    if (i >= total) break;
-    float a = acc[u];
-    int g = (int)(i % Cg);
-    long long t = i / Cg;
-    int p_ = (int)(t % Cp);
-    long long tap = t / Cp;
-    float* o = out + tap * st + p_ * sp + g * sg;
-    *o = J[10] ? *o + a : a;
+  if (contiguous) {
+    __syncthreads();
+    float* o = out + p * sp;
+    for (int j = threadIdx.x; j < E; j += 256) o[j] = J[10] ? o[j] + rowbuf[j] : rowbuf[j];
   }
 }
 

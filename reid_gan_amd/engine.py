@@ -159,7 +159,7 @@ class Ctx:
 
     def add_wgrad_reduce(self, slab_off, out: torch.Tensor, splitk, taps, Cp, Cg, st, sp, sg, accumulate=False):
         j = self.wreds.add([0, out.data_ptr(), splitk, taps * Cp * Cg, taps, Cp, Cg, st, sp, sg, int(accumulate)],
-                           taps * Cp * Cg)
+                           nblocks=Cp)
         self._wred_slab.append((j, slab_off))
 
     def need_tmp(self, n):

@@ -118,10 +118,11 @@ class JobTable:
         self.words, self.rows, self.totals = words, [], []
         self.jobs = self.blockmap = None
 
-    def add(self, row, total: int) -> int:
+    def add(self, row, total: int = 0, nblocks: Optional[int] = None) -> int:
+        """total: elements (one block per 2048); or nblocks: the job's own block count (blockmap[b][1] = 0..n-1)."""
         assert len(row) == self.words and self.jobs is None
         self.rows.append([int(v) for v in row])
-        self.totals.append(int(total))
+        self.totals.append(int(nblocks) if nblocks is not None else (int(total) + JOB_CHUNK - 1) // JOB_CHUNK)
         return len(self.rows) - 1
 
     def finalize(self, device):
@@ -130,7 +131,7 @@ class JobTable:
             return
         bm = []
         for j, t in enumerate(self.totals):
-            bm.extend((j, c) for c in range((t + JOB_CHUNK - 1) // JOB_CHUNK))
+            bm.extend((j, c) for c in range(t))
         self.jobs = torch.from_numpy(np.asarray(self.rows, dtype=np.int64)).to(device)
         self.blockmap = torch.from_numpy(np.asarray(bm, dtype=np.int32).reshape(-1)).to(device)
         self.nblocks = len(bm)

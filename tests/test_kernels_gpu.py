@@ -221,9 +221,15 @@ def test_job_table_pack_and_reduce_match_single_calls():
         oref = torch.zeros(co, ci, kh, kw, device=DEV)
         ogot = torch.full_like(oref, 0.5)
         ops.wgrad_reduce(slab, splitk, t, co, ci, oref, 1, ci * t, t)
-        jobs_r.add([slab.data_ptr(), ogot.data_ptr(), splitk, t * co * ci, t, co, ci, 1, ci * t, t, 0], t * co * ci)
+        jobs_r.add([slab.data_ptr(), ogot.data_ptr(), splitk, t * co * ci, t, co, ci, 1, ci * t, t, 0], nblocks=co)
         keep += [w, slab]
         checks += [(ref, got), (oref, ogot)]
+    # a master laid out [tap][p][g] (not the [p][g][tap] rows of conv weights): the scattered-store path
+    slab = torch.randn(5, 4, 24, 40, generator=g).to(DEV)
+    oref, ogot = torch.zeros(4, 24, 40, device=DEV), torch.full((4, 24, 40), 0.25, device=DEV)
+    ops.wgrad_reduce(slab, 5, 4, 24, 40, oref, 24 * 40, 40, 1)
+    jobs_r.add([slab.data_ptr(), ogot.data_ptr(), 5, 4 * 24 * 40, 4, 24, 40, 24 * 40, 40, 1, 0], nblocks=24)
+    keep.append(slab); checks.append((oref, ogot))
     # an fp32 destination with a row pitch (a [rows][pitch] matrix filled in column blocks)
     src = torch.randn(40, 24, generator=g).to(DEV)
     dst = torch.zeros(40, 64, device=DEV)
