@@ -125,6 +125,7 @@ class Ctx:
         self.f32_elems = 0            # shared fp32 scratch (BN backward partial rows, column sums)
         self._stats_req: List[Tuple[object, str, int]] = []
         self.chain = False                 # True: no activation gradient has two writers, nothing needs zeroing
+        self.build_lane = 0                # lane (stream + scratch set) the layers being built will run on
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
         self.wreds = ops.JobTable(11)      # every weight-gradient slab reduction: one launch (end_backward)
         self._wred_slab: List[Tuple[int, int]] = []      # (job, slab offset) patched once the arena exists
@@ -185,12 +186,15 @@ class Ctx:
             self.wreds.rows[j][0] = self.slab.data_ptr() + 4 * off
         self.packs.finalize(dev)
         self.wreds.finalize(dev)
-        self.tmp = torch.empty(max(self.tmp_elems, 8), dtype=torch.bfloat16, device=dev)
-        self.f32 = torch.empty(max(self.f32_elems, 4), dtype=F32, device=dev)
+        # one scratch set per lane: branches of a Par run concurrently on their own streams
+        self.tmps = [torch.empty(max(self.tmp_elems, 8), dtype=torch.bfloat16, device=dev) for _ in range(N_LANES)]
+        self.f32s = [torch.empty(max(self.f32_elems, 4), dtype=F32, device=dev) for _ in range(N_LANES)]
+        self.tmp, self.f32 = self.tmps[0], self.f32s[0]
 
-    def tmp_view(self, N, H, W, C) -> View:
-        assert N * H * W * C <= self.tmp.numel()
-        return View(self.tmp, self.tmp.data_ptr(), C, C, N, H, W)
+    def tmp_view(self, N, H, W, C, lane: int = 0) -> View:
+        t = self.tmps[lane]
+        assert N * H * W * C <= t.numel()
+        return View(t, t.data_ptr(), C, C, N, H, W)
 
     def slab_at(self, off) -> int:
         return self.slab.data_ptr() + 4 * off
@@ -209,6 +213,17 @@ class Ctx:
     def end_backward(self):
         """Reduce the weight-gradient slabs of every layer into the master gradients (one launch)."""
         ops.wgrad_reduce_jobs(self.wreds)
+
+
+N_LANES = 4
+_side_streams: List["torch.cuda.Stream"] = []
+
+
+def side_stream(lane: int):
+    """Process-wide side streams for lanes 1..N_LANES-1 (lane 0 is the caller's current stream)."""
+    while len(_side_streams) < N_LANES - 1:
+        _side_streams.append(torch.cuda.Stream())
+    return _side_streams[lane - 1]
 
 
 class _Fused:
@@ -346,7 +361,7 @@ class ConvBN:
 
     def __init__(self, ctx: Ctx, prefix: str, cin, cout, k, stride, pad, xin: Slot, out: Slot, deconv=False,
                  accumulate=False, need_dx=True, conv_key=None, bn_key=None):
-        self.ctx, self.prefix = ctx, prefix
+        self.ctx, self.prefix, self.lane = ctx, prefix, ctx.build_lane
         conv_key = conv_key or (prefix + (".deconv" if deconv else ".conv"))
         self.bn = bn_key or (prefix + ".bn")
         self.core = ConvCore(ctx, conv_key + ".weight", cin, cout, k, stride, pad, deconv, xin, need_dx)
@@ -376,13 +391,22 @@ class ConvBN:
 
     def backward(self):
         """Reads out.g; writes weight / BN gradients; accumulates into xin.g when need_dx."""
+        self.backward_local()
+        self.backward_input()
+
+    def backward_local(self):
+        """Everything that touches only this layer's own buffers (safe to run beside sibling branches)."""
         ctx, c, st = self.ctx, self.core, self.ctx.st
-        draw = ctx.tmp_view(c.N, c.Ho, c.Wo, c.cout)
+        draw = ctx.tmp_view(c.N, c.Ho, c.Wo, c.cout, self.lane)
         ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
-                        ctx.f32, st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True)
+                        ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True)
         c.wgrad(draw)
+
+    def backward_input(self):
+        """xin.g += data gradient; the lane's temp still holds the pre-BN gradient from backward_local()."""
+        c = self.core
         if c.need_dx:
-            c.dgrad(draw, c.xin.g)
+            c.dgrad(self.ctx.tmp_view(c.N, c.Ho, c.Wo, c.cout, self.lane), c.xin.g)
 
 
 class ConvBNC1:
@@ -436,9 +460,14 @@ class ConvPlain:
         self.core.conv(self.out.v)
 
     def backward(self):
-        c = self.core
-        c.wgrad(self.out.g)
-        c.dgrad(self.out.g, c.xin.g)
+        self.backward_local()
+        self.backward_input()
+
+    def backward_local(self):
+        self.core.wgrad(self.out.g)
+
+    def backward_input(self):
+        self.core.dgrad(self.out.g, self.core.xin.g)
 
 
 class Pool:
@@ -450,6 +479,11 @@ class Pool:
 
     def backward(self):
         ops.pool_bwd(None if self.mode == ops.POOL_AVG3 else self.xin.v, self.out.g, self.xin.g, self.mode)
+
+    def backward_local(self):
+        pass
+
+    backward_input = backward
 
 
 class Upsample:
@@ -480,6 +514,63 @@ class Seq:
     def backward(self):
         for l in reversed(self.layers):
             l.backward()
+
+    def backward_local(self):
+        """All but the write into this sequence's input gradient (which sibling branches also write)."""
+        for l in reversed(self.layers[1:]):
+            l.backward()
+        self.layers[0].backward_local()
+
+    def backward_input(self):
+        self.layers[0].backward_input()
+
+
+class Par:
+    """Branches that read one tensor and write disjoint channel slices of another (the Inception branches,
+    src/rinet.py:225-252 and alike).  Each branch runs on its own stream, with its own scratch lane; the streams
+    fork from and rejoin the caller's stream, so a graph capture records the branches as parallel paths.  The
+    branches' gradients w.r.t. the shared input are added one after another once they have joined."""
+
+    def __init__(self, ctx: Ctx, branches: List[Seq]):
+        assert 1 <= len(branches) <= N_LANES
+        self.ctx, self.branches = ctx, branches
+
+    def _run(self, fn_name: str):
+        if os.environ.get("RIED_SERIAL_BRANCHES"):          # debugging aid: one stream
+            for b in self.branches:
+                getattr(b, fn_name)()
+            return
+        main = torch.cuda.current_stream()
+        for lane in range(1, len(self.branches)):
+            s = side_stream(lane)
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                getattr(self.branches[lane], fn_name)()
+        getattr(self.branches[0], fn_name)()
+        for lane in range(1, len(self.branches)):
+            main.wait_stream(side_stream(lane))
+
+    def forward(self):
+        self._run("forward")
+
+    def backward(self):
+        self._run("backward_local")
+        for b in self.branches:
+            b.backward_input()
+
+
+class _Lane:
+    """with _Lane(ctx, i): layers built inside run on lane i (stream and scratch set)."""
+
+    def __init__(self, ctx: Ctx, lane: int):
+        self.ctx, self.lane = ctx, lane
+
+    def __enter__(self):
+        self.ctx.build_lane = self.lane
+        return Seq()
+
+    def __exit__(self, *a):
+        self.ctx.build_lane = 0
 
 
 class Identity:
@@ -526,15 +617,20 @@ def inception_a(ctx, prefix, xin: Slot, out: Slot, cin, has_ds) -> Seq:
     """src/rinet.py:207-252: out = cat(32|32|48|16) + identity."""
     s = Seq()
     _residual_head(ctx, s, prefix, xin, out, cin, 128, has_ds)
-    _chain(ctx, s, prefix, [("branch1x1", cin, 32, 1, 1, 0)], xin, out.sub(0, 32), accumulate=True)
-    _chain(ctx, s, prefix, [("branch3x3_1", cin, 16, 1, 1, 0), ("branch3x3_2", 16, 32, 3, 1, 1)], xin,
-           out.sub(32, 64), accumulate=True)
-    _chain(ctx, s, prefix, [("branch3x3dbl_1", cin, 32, 1, 1, 0), ("branch3x3dbl_2", 32, 48, 3, 1, 1),
-                            ("branch3x3dbl_3", 48, 48, 3, 1, 1)], xin, out.sub(64, 112), accumulate=True)
-    N, H, W, _ = xin.shape
-    pooled = Slot(ctx.act(N, H, W, cin))
-    s.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
-    _chain(ctx, s, prefix, [("branch_pool", cin, 16, 1, 1, 0)], pooled, out.sub(112, 128), accumulate=True)
+    with _Lane(ctx, 0) as b0:      # the longest branch on the caller's stream
+        _chain(ctx, b0, prefix, [("branch3x3dbl_1", cin, 32, 1, 1, 0), ("branch3x3dbl_2", 32, 48, 3, 1, 1),
+                                 ("branch3x3dbl_3", 48, 48, 3, 1, 1)], xin, out.sub(64, 112), accumulate=True)
+    with _Lane(ctx, 1) as b1:
+        _chain(ctx, b1, prefix, [("branch3x3_1", cin, 16, 1, 1, 0), ("branch3x3_2", 16, 32, 3, 1, 1)], xin,
+               out.sub(32, 64), accumulate=True)
+    with _Lane(ctx, 2) as b2:
+        _chain(ctx, b2, prefix, [("branch1x1", cin, 32, 1, 1, 0)], xin, out.sub(0, 32), accumulate=True)
+    with _Lane(ctx, 3) as b3:
+        N, H, W, _ = xin.shape
+        pooled = Slot(ctx.act(N, H, W, cin))
+        b3.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
+        _chain(ctx, b3, prefix, [("branch_pool", cin, 16, 1, 1, 0)], pooled, out.sub(112, 128), accumulate=True)
+    s.add(Par(ctx, [b0, b1, b2, b3]))
     return s
 
 
@@ -543,16 +639,21 @@ def inception_c(ctx, prefix, xin: Slot, out: Slot, cin, c7, has_ds) -> Seq:
     s = Seq()
     _residual_head(ctx, s, prefix, xin, out, cin, 256, has_ds)
     h, v = ((1, 7), 1, (0, 3)), ((7, 1), 1, (3, 0))
-    _chain(ctx, s, prefix, [("branch1x1", cin, 64, 1, 1, 0)], xin, out.sub(0, 64), accumulate=True)
-    _chain(ctx, s, prefix, [("branch7x7_1", cin, c7, 1, 1, 0), ("branch7x7_2", c7, c7, *h),
-                            ("branch7x7_3", c7, 64, *v)], xin, out.sub(64, 128), accumulate=True)
-    _chain(ctx, s, prefix, [("branch7x7dbl_1", cin, c7, 1, 1, 0), ("branch7x7dbl_2", c7, c7, *v),
-                            ("branch7x7dbl_3", c7, c7, *h), ("branch7x7dbl_4", c7, c7, *v),
-                            ("branch7x7dbl_5", c7, 64, *h)], xin, out.sub(128, 192), accumulate=True)
-    N, H, W, _ = xin.shape
-    pooled = Slot(ctx.act(N, H, W, cin))
-    s.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
-    _chain(ctx, s, prefix, [("branch_pool", cin, 64, 1, 1, 0)], pooled, out.sub(192, 256), accumulate=True)
+    with _Lane(ctx, 0) as b0:
+        _chain(ctx, b0, prefix, [("branch7x7dbl_1", cin, c7, 1, 1, 0), ("branch7x7dbl_2", c7, c7, *v),
+                                 ("branch7x7dbl_3", c7, c7, *h), ("branch7x7dbl_4", c7, c7, *v),
+                                 ("branch7x7dbl_5", c7, 64, *h)], xin, out.sub(128, 192), accumulate=True)
+    with _Lane(ctx, 1) as b1:
+        _chain(ctx, b1, prefix, [("branch7x7_1", cin, c7, 1, 1, 0), ("branch7x7_2", c7, c7, *h),
+                                 ("branch7x7_3", c7, 64, *v)], xin, out.sub(64, 128), accumulate=True)
+    with _Lane(ctx, 2) as b2:
+        _chain(ctx, b2, prefix, [("branch1x1", cin, 64, 1, 1, 0)], xin, out.sub(0, 64), accumulate=True)
+    with _Lane(ctx, 3) as b3:
+        N, H, W, _ = xin.shape
+        pooled = Slot(ctx.act(N, H, W, cin))
+        b3.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
+        _chain(ctx, b3, prefix, [("branch_pool", cin, 64, 1, 1, 0)], pooled, out.sub(192, 256), accumulate=True)
+    s.add(Par(ctx, [b0, b1, b2, b3]))
     return s
 
 
@@ -561,17 +662,26 @@ def inception_e(ctx, prefix, xin: Slot, out: Slot, cin, has_ds) -> Seq:
     s = Seq()
     _residual_head(ctx, s, prefix, xin, out, cin, 1024, has_ds)
     N, H, W, _ = xin.shape
-    _chain(ctx, s, prefix, [("branch1x1", cin, 160, 1, 1, 0)], xin, out.sub(0, 160), accumulate=True)
-    b3 = _chain(ctx, s, prefix, [("branch3x3_1", cin, 192, 1, 1, 0)], xin, Slot(ctx.act(N, H, W, 192)))
-    _chain(ctx, s, prefix, [("branch3x3_2a", 192, 192, (1, 3), 1, (0, 1))], b3, out.sub(160, 352), accumulate=True)
-    _chain(ctx, s, prefix, [("branch3x3_2b", 192, 192, (3, 1), 1, (1, 0))], b3, out.sub(352, 544), accumulate=True)
-    bd = _chain(ctx, s, prefix, [("branch3x3dbl_1", cin, 224, 1, 1, 0), ("branch3x3dbl_2", 224, 192, 3, 1, 1)], xin,
-                Slot(ctx.act(N, H, W, 192)))
-    _chain(ctx, s, prefix, [("branch3x3dbl_3a", 192, 192, (1, 3), 1, (0, 1))], bd, out.sub(544, 736), accumulate=True)
-    _chain(ctx, s, prefix, [("branch3x3dbl_3b", 192, 192, (3, 1), 1, (1, 0))], bd, out.sub(736, 928), accumulate=True)
-    pooled = Slot(ctx.act(N, H, W, cin))
-    s.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
-    _chain(ctx, s, prefix, [("branch_pool", cin, 96, 1, 1, 0)], pooled, out.sub(928, 1024), accumulate=True)
+    with _Lane(ctx, 0) as b0:
+        bd = _chain(ctx, b0, prefix, [("branch3x3dbl_1", cin, 224, 1, 1, 0), ("branch3x3dbl_2", 224, 192, 3, 1, 1)],
+                    xin, Slot(ctx.act(N, H, W, 192)))
+        _chain(ctx, b0, prefix, [("branch3x3dbl_3a", 192, 192, (1, 3), 1, (0, 1))], bd, out.sub(544, 736),
+               accumulate=True)
+        _chain(ctx, b0, prefix, [("branch3x3dbl_3b", 192, 192, (3, 1), 1, (1, 0))], bd, out.sub(736, 928),
+               accumulate=True)
+    with _Lane(ctx, 1) as b1:
+        b3 = _chain(ctx, b1, prefix, [("branch3x3_1", cin, 192, 1, 1, 0)], xin, Slot(ctx.act(N, H, W, 192)))
+        _chain(ctx, b1, prefix, [("branch3x3_2a", 192, 192, (1, 3), 1, (0, 1))], b3, out.sub(160, 352),
+               accumulate=True)
+        _chain(ctx, b1, prefix, [("branch3x3_2b", 192, 192, (3, 1), 1, (1, 0))], b3, out.sub(352, 544),
+               accumulate=True)
+    with _Lane(ctx, 2) as b2:
+        _chain(ctx, b2, prefix, [("branch1x1", cin, 160, 1, 1, 0)], xin, out.sub(0, 160), accumulate=True)
+    with _Lane(ctx, 3) as b4:
+        pooled = Slot(ctx.act(N, H, W, cin))
+        b4.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
+        _chain(ctx, b4, prefix, [("branch_pool", cin, 96, 1, 1, 0)], pooled, out.sub(928, 1024), accumulate=True)
+    s.add(Par(ctx, [b0, b1, b2, b4]))
     return s
 
 
@@ -587,29 +697,33 @@ def _grid_tail(ctx, s, prefix, xin: Slot, out_slice: Slot, cin, cs, decoder):
 
 def inception_b(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
     """src/rinet.py:254-291: cat(64 | 64 | maxpool(cin) or sample(128))."""
-    s = Seq()
     k = 4 if decoder else 3
-    _chain(ctx, s, prefix, [("branch3x3_1", cin, 32, 1, 1, 0), ("branch3x3_2", 32, 64, k, 2, 1)], xin,
-           out.sub(0, 64), deconv=decoder)
-    _chain(ctx, s, prefix, [("branch3x3dbl_1", cin, 32, 1, 1, 0), ("branch3x3dbl_2", 32, 48, 3, 1, 1),
-                            ("branch3x3dbl_3", 48, 64, k, 2, 1)], xin, out.sub(64, 128), deconv=decoder)
+    with _Lane(ctx, 0) as b0:
+        _chain(ctx, b0, prefix, [("branch3x3dbl_1", cin, 32, 1, 1, 0), ("branch3x3dbl_2", 32, 48, 3, 1, 1),
+                                 ("branch3x3dbl_3", 48, 64, k, 2, 1)], xin, out.sub(64, 128), deconv=decoder)
+    with _Lane(ctx, 1) as b1:
+        _chain(ctx, b1, prefix, [("branch3x3_1", cin, 32, 1, 1, 0), ("branch3x3_2", 32, 64, k, 2, 1)], xin,
+               out.sub(0, 64), deconv=decoder)
     cs = 128 if decoder else cin
-    _grid_tail(ctx, s, prefix, xin, out.sub(128, 128 + cs), cin, cs, decoder)
-    return s
+    with _Lane(ctx, 2) as b2:
+        _grid_tail(ctx, b2, prefix, xin, out.sub(128, 128 + cs), cin, cs, decoder)
+    return Seq([Par(ctx, [b0, b1, b2])])
 
 
 def inception_d(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
     """src/rinet.py:349-387: cat(128 | 128 | maxpool(cin) or sample(256))."""
-    s = Seq()
     k = 4 if decoder else 3
-    _chain(ctx, s, prefix, [("branch3x3_1", cin, 64, 1, 1, 0), ("branch3x3_2", 64, 128, k, 2, 1)], xin,
-           out.sub(0, 128), deconv=decoder)
-    _chain(ctx, s, prefix, [("branch7x7x3_1", cin, 128, 1, 1, 0), ("branch7x7x3_2", 128, 128, (1, 7), 1, (0, 3)),
-                            ("branch7x7x3_3", 128, 128, (7, 1), 1, (3, 0)), ("branch7x7x3_4", 128, 128, k, 2, 1)],
-           xin, out.sub(128, 256), deconv=decoder)
+    with _Lane(ctx, 0) as b0:
+        _chain(ctx, b0, prefix, [("branch7x7x3_1", cin, 128, 1, 1, 0), ("branch7x7x3_2", 128, 128, (1, 7), 1, (0, 3)),
+                                 ("branch7x7x3_3", 128, 128, (7, 1), 1, (3, 0)),
+                                 ("branch7x7x3_4", 128, 128, k, 2, 1)], xin, out.sub(128, 256), deconv=decoder)
+    with _Lane(ctx, 1) as b1:
+        _chain(ctx, b1, prefix, [("branch3x3_1", cin, 64, 1, 1, 0), ("branch3x3_2", 64, 128, k, 2, 1)], xin,
+               out.sub(0, 128), deconv=decoder)
     cs = 256 if decoder else cin
-    _grid_tail(ctx, s, prefix, xin, out.sub(256, 256 + cs), cin, cs, decoder)
-    return s
+    with _Lane(ctx, 2) as b2:
+        _grid_tail(ctx, b2, prefix, xin, out.sub(256, 256 + cs), cin, cs, decoder)
+    return Seq([Par(ctx, [b0, b1, b2])])
 
 
 # --------------------------------------------------------------------------- generator

@@ -1,0 +1,48 @@
+"""Time G forward+backward, D forward+backward and VGG forward+backward alone (graph replays) on the GPU box."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from reid_gan_amd import engine, ops
+from reid_gan_amd.engine import State, Generator, Discriminator, Vgg
+from reid_gan_amd.synth import synth_batch
+
+B = 128
+g, d, vgg = bench.synth_states()
+x, y = synth_batch(B, 64, seed=1)
+x, y = x.cuda(), y.cuda()
+
+def timeit(name, fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        fn()
+    gr.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        gr.replay()
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name}: {e0.elapsed_time(e1) / reps:.3f} ms", flush=True)
+
+gs = State(g, "cuda"); G = Generator(gs, B, 64, 64)
+dout = torch.randn(B, 1, 64, 64, device="cuda")
+timeit("G forward", lambda: G.forward(x))
+def gfb():
+    G.forward(x); gs.zero_grad(); G.backward(dout)
+timeit("G forward+backward", gfb)
+ds = State(d, "cuda"); D = Discriminator(ds, 2 * B, 64, 64)
+din = torch.cat([y, x], 0).contiguous()
+timeit("D forward", lambda: D.forward(din))
+def dfb():
+    out = D.forward(din); ds.zero_grad(); ops.fill(out.g, 1e-3); D.backward(0, 2 * B, wgrad=True)
+timeit("D forward+backward(wgrad)", dfb)
+def dgb():
+    out = D.forward(din); ops.fill(out.g.images(B, 2 * B), 1e-3); D.backward(B, 2 * B, wgrad=False, dimg=dout)
+timeit("D forward+backward(data only, half)", dgb)
+V = Vgg(vgg, B, 64, 64)
+loss = torch.zeros(1, device="cuda")
+def vfb():
+    V.forward(din); V.loss_and_seed(loss, 0.3); V.backward(dout)
+timeit("VGG forward", lambda: V.forward(din))
+timeit("VGG forward+loss+backward", vfb)
