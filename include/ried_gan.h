@@ -48,6 +48,14 @@ int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long 
                 int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
                 const float* bias, int act, float* stats, int accumulate, int out_f32, float* y2, long long ldy2,
                 const void* mask, long long ldmask, float mask_slope, int stats_post, ried_stream_t stream);
+/* BasicConv2d / BasicDeconv2d (src/rinet.py:183-205) up to the BatchNorm statistics: y = raw bf16 conv result,
+ * stats = partial rows as in ried_conv2d, and the last block to finish reduces them into save = (mean,
+ * 1/sqrt(var+eps)) [2][Cout] and updates running_mean / running_var / num_batches_tracked (torch train-mode
+ * semantics; any of the three may be NULL).  counter: one zero-initialised unsigned per layer (left at zero). */
+int ried_conv2d_bn(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
+                   int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
+                   float* stats, unsigned* counter, float eps, float momentum, float* save, float* running_mean,
+                   float* running_var, long long* num_batches_tracked, ried_stream_t stream);
 /* out[c] += sum over rows of stats[r][0][c] (stats: [nrows][2][C], as written by ried_conv2d) */
 int ried_stat_rows_sum(const float* stats, int nrows, int C, float* out, ried_stream_t stream);
 
@@ -100,10 +108,12 @@ int ried_bn_eval_stats(const float* running_mean, const float* running_var, int 
 int ried_bn_apply(const void* x, long long ldx, void* y, long long ldy, long long npix, int C, const float* save,
                   const float* gamma, const float* beta, int relu, int accumulate, ried_stream_t stream);
 /* dx = d(loss)/d(conv output) from dy = d(loss)/d(bn+relu output); scratch: fp32
- * [ried_bn_backward_scratch_floats(C)] (need not be zeroed); dgamma/dbeta may be NULL. */
+ * [ried_bn_backward_scratch_floats(C)] (need not be zeroed); dgamma/dbeta may be NULL; counter: NULL, or one
+ * zero-initialised unsigned per layer (left at zero) - the last block of the reduction then finishes the sums. */
 int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
                      long long npix, int C, const float* save, const float* gamma, const float* beta, int relu,
-                     float* scratch, float* dgamma, float* dbeta, int accumulate, ried_stream_t stream);
+                     float* scratch, float* dgamma, float* dbeta, int accumulate, unsigned* counter,
+                     ried_stream_t stream);
 long long ried_bn_backward_scratch_floats(int C);
 
 /* ---- pooling / upsampling ------------------------------------------------------------------------------------- */
@@ -174,6 +184,14 @@ int ried_sn_sigma(const float* Wm, int R, int K, float* u, float* v, float* sigm
 /* dW (+)= (dWsn - (sum(dWsn*W)/sigma) u v^T)/sigma ; scratch1: one fp32 */
 int ried_sn_backward(const float* dWsn, const float* Wm, const float* u, const float* v, const float* sigma, int R,
                      int K, float* dW, float* scratch1, int accumulate, ried_stream_t stream);
+/* Job-table forms: all spectral-norm layers of a network per launch.  job = 10 64-bit words: W, u, v, sigma,
+ * t (scratch fp32 [max(K, 64)]), s (scratch fp32 [R]), R, K, dWsn, dW.  Block maps are (job, chunk) pairs: map_cols
+ * 64 columns of W per block, map_rows 4 rows per block, map_dot one of 64 slices of R*K per block, map_apply 2048
+ * elements per block. */
+int ried_sn_sigma_jobs(const long long* jobs, int njobs, const int* map_cols, int nblocks_cols, const int* map_rows,
+                       int nblocks_rows, int power_iter, float eps, ried_stream_t stream);
+int ried_sn_backward_jobs(const long long* jobs, const int* map_dot, int nblocks_dot, const int* map_apply,
+                          int nblocks_apply, int accumulate, ried_stream_t stream);
 
 /* ---- losses ---------------------------------------------------------------------------------------------------- */
 /* nn.MSELoss on one VGG tap (src/loss.py:185-187): a, b fp32 [n]; loss[0] += loss_scale*sum (a-b)^2;

@@ -41,7 +41,7 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[str, List[Tuple[str
 
 
 def _ctype_of(t: str):
-    if "*" in t:
+    if "*" in t:      # every pointer, whatever it points to, is passed as an address
         return ctypes.c_void_p
     t = t.replace("const ", "").strip()
     return _CTYPES[t]

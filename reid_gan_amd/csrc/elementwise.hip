@@ -8,6 +8,7 @@
 // Views let producers write straight into channel slices of a concatenation
 // buffer, which removes every torch.cat of src/rinet.py:88-90,245,291,340,387,418-438.
 #include "common.h"
+#include "bn_common.h"
 
 #define EW_THREADS 256
 
@@ -329,8 +330,10 @@ extern "C" int ried_bn_apply(const void* x, long long ldx, void* y, long long ld
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx, long long npix, int C,
     const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
-    float* __restrict__ sums) {
+    float* __restrict__ sums, unsigned* counter, float* __restrict__ fin, float* dgamma, float* dbeta,
+    int accumulate) {
   __shared__ float red[EW_THREADS][17];           // per-thread partials, padded against bank conflicts
+  __shared__ int last_flag;
   ChanWalk w(C);
   const int c = w.c;
   float s1[8], s2[8];
@@ -367,8 +370,12 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
     int t0 = ch >> 3, q = (ch & 7) + 8 * k;
     float acc = 0.f;
     for (int pl = 0; pl < PPB; ++pl) acc += red[pl * CC + t0][q];
-    row[j] = acc;
+    if (counter) ried_publish(&row[j], acc);      // read by the last block of this launch: write-through
+    else row[j] = acc;
   }
+  // the last block to arrive reduces the rows (instead of a separate, dependent launch)
+  if (counter && ried_last_block(counter, gridDim.x, &last_flag))
+    bn_bwd_finish_rows(sums, gridDim.x, C, fin, dgamma, dbeta, accumulate, &red[0][0]);
 }
 
 // backward pass 2: dx = gamma*invstd*(g - s1/n - xhat*s2/n)
@@ -421,10 +428,12 @@ __global__ __launch_bounds__(ROWRED_THREADS) void bn_bwd_finish_kernel(const flo
 
 #define BN_BWD_MAX_ROWS 1024
 // scratch: fp32 [(BN_BWD_MAX_ROWS + 1) * 2 * C] (need not be zeroed).  dgamma/dbeta may be null.
+// counter: null, or one zero-initialised unsigned (left at zero): the reduction's last block then finishes the
+// sums itself instead of a separate launch.
 extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
                                 long long npix, int C, const float* save, const float* gamma, const float* beta,
                                 int relu, float* scratch, float* dgamma, float* dbeta, int accumulate,
-                                hipStream_t stream) {
+                                unsigned* counter, hipStream_t stream) {
   CHECK_VIEW("ried_bn_backward", dy, lddy, C);
   CHECK_VIEW("ried_bn_backward", x, ldx, C);
   CHECK_VIEW("ried_bn_backward", dx, lddx, C);
@@ -432,10 +441,13 @@ extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, l
   RIED_CHECK_ARG(C <= 8 * EW_THREADS, "ried_bn_backward: C too large");
   int grid = chan_grid(npix, C, 4, BN_BWD_MAX_ROWS);
   float* fin = scratch + (long long)BN_BWD_MAX_ROWS * 2 * C;
+  float* dg = (dgamma && dbeta) ? dgamma : nullptr;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)dy, lddy,
-                     (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, scratch);
-  hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(ceil_div(C, 32)), dim3(ROWRED_THREADS), 0, stream, scratch, grid, C,
-                     fin, (dgamma && dbeta) ? dgamma : nullptr, dbeta, accumulate);
+                     (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, scratch, counter, fin, dg, dbeta,
+                     accumulate);
+  if (!counter)
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(ceil_div(C, 32)), dim3(ROWRED_THREADS), 0, stream, scratch, grid,
+                       C, fin, dg, dbeta, accumulate);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chan_grid(npix, C, 2, 8192)), dim3(EW_THREADS), 0, stream,
                      (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (bf16_t*)dx, lddx, npix, C, save, gamma, beta,
                      relu, fin);

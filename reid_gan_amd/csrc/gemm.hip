@@ -20,6 +20,7 @@
 // (reference: src/rinet.py:183-205, 131-148; src/loss.py:69-87), and the
 // batched products of the self-attention layers (src/rinet.py:162-181).
 #include "common.h"
+#include "bn_common.h"
 
 enum { OP_PLAIN_K = 0, OP_PLAIN_TR = 1, OP_GATHER_K = 2, OP_GATHER_TR = 3 };
 
@@ -53,6 +54,7 @@ struct GemmEpilogue {
   long long ld_mask;       // fused into the data gradient that produces the tensor); applied after accumulate
   float mask_slope;
   int stats_post;          // stats = column sums of the final values (bias gradient) instead of the raw results
+  BnFinalize fin;          // fin.counter != null: the last block to finish turns the stats rows into BN statistics
   int phase_mode, Wo_full, HoWo_full, Hq, Wq, sh, sw;   // logical row -> physical pixel
 };
 
@@ -383,10 +385,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
           int ml = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
           int m = m0 + ml;
           if (m < P.M) {
-            row[m] = ssum[i][q] + red[ml];
-            row[P.M + m] = ssq[i][q] + red[BM + ml];
+            if (E.fin.counter) {           // read by the last block of this launch: write-through
+              ried_publish(&row[m], ssum[i][q] + red[ml]);
+              ried_publish(&row[P.M + m], ssq[i][q] + red[BM + ml]);
+            } else {
+              row[m] = ssum[i][q] + red[ml];
+              row[P.M + m] = ssq[i][q] + red[BM + ml];
+            }
           }
         }
+    }
+    if (E.fin.counter) {       // fused BatchNorm finalize: saves a dependent launch per layer
+      float* scratch = reinterpret_cast<float*>(smem) + 1024;
+      if (ried_last_block(E.fin.counter, gridDim.x * gridDim.y * gridDim.z, reinterpret_cast<int*>(smem) + 768))
+        bn_finalize_rows(E.stats, P.M, E.fin, scratch);
     }
   }
 }
@@ -719,11 +731,11 @@ static void default_epilogue(GemmEpilogue& E) {
 // Conv2d forward (transposed = 0) or ConvTranspose2d forward / strided-conv data gradient
 // (transposed = 1).  x: NHWC bf16 [nimg][H][W][ldx], channels 0..Cin-1 used.
 // w: packed bf16 [Cout][kh][kw][Cin].  y: NHWC [nimg][Ho][Wo][ldy], channels 0..Cout-1 written.
-extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
-                           int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
-                           int transposed, const float* bias, int act, float* stats, int accumulate, int out_f32,
-                           float* y2, long long ldy2, const void* mask, long long ldmask, float mask_slope,
-                           int stats_post, hipStream_t stream) {
+static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
+                       int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                       int transposed, const float* bias, int act, float* stats, int accumulate, int out_f32,
+                       float* y2, long long ldy2, const void* mask, long long ldmask, float mask_slope,
+                       int stats_post, const BnFinalize* fin, hipStream_t stream) {
   RIED_CHECK_ARG(x && w && y, "ried_conv2d: null pointer");
   RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
   RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
@@ -774,6 +786,10 @@ extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y,
   ConvTile t = choose_conv_tile(Cout, npix, phases);
   P.tiles_m = ceil_div(Cout, t.bm);
   dim3 grid(P.tiles_m * ceil_div(npix, t.bn), phases, 1);
+  if (fin) {
+    P.E.fin = *fin;
+    P.E.fin.nrows = phases * ceil_div(npix, t.bn);
+  }
 #define RIED_CONV_CASE(BM_, BN_, NST_)                                                                  \
   if (t.bm == BM_ && t.bn == BN_ && t.nst == NST_) {                                                    \
     hipLaunchKernelGGL((conv_glds_kernel<BM_, BN_, NST_>), grid, dim3(256), 0, stream, P);              \
@@ -787,6 +803,33 @@ extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y,
   RIED_CHECK_ARG(launched, "ried_conv2d: no kernel for tile %dx%dx%d", t.bm, t.bn, t.nst);
   RIED_CHECK_LAUNCH("ried_conv2d");
   return RIED_OK;
+}
+
+extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
+                           int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                           int transposed, const float* bias, int act, float* stats, int accumulate, int out_f32,
+                           float* y2, long long ldy2, const void* mask, long long ldmask, float mask_slope,
+                           int stats_post, hipStream_t stream) {
+  return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, bias, act,
+                     stats, accumulate, out_f32, y2, ldy2, mask, ldmask, mask_slope, stats_post, nullptr, stream);
+}
+
+// Convolution (or transposed convolution) of a BasicConv2d / BasicDeconv2d block (src/rinet.py:183-205) with the
+// train-mode BatchNorm statistics fused: y = raw bf16 result; stats = partial rows as in ried_conv2d; the last
+// block to finish reduces them into save = (mean, 1/sqrt(var+eps)) and updates the running statistics.
+// counter: one zero-initialised unsigned per layer (left at zero).
+extern "C" int ried_conv2d_bn(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H,
+                              int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                              int transposed, float* stats, unsigned* counter, float eps, float momentum, float* save,
+                              float* running_mean, float* running_var, long long* num_batches_tracked,
+                              hipStream_t stream) {
+  RIED_CHECK_ARG(stats && counter && save, "ried_conv2d_bn: null pointer");
+  BnFinalize f;
+  f.counter = counter; f.save = save; f.running_mean = running_mean; f.running_var = running_var;
+  f.nbt = num_batches_tracked; f.count = (float)((long long)nimg * Ho * Wo); f.eps = eps; f.momentum = momentum;
+  f.nrows = 0;
+  return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, nullptr, 0,
+                     stats, 0, 0, nullptr, 0, nullptr, 0, 0.f, 0, &f, stream);
 }
 
 // Weight gradient partial sums.  g: the tensor that is gathered through the kernel window

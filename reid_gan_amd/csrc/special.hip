@@ -469,6 +469,146 @@ extern "C" int ried_sn_backward(const float* dWsn, const float* Wm, const float*
 }
 
 // ---------------------------------------------------------------------------
+// Job-table forms of the two functions above: every spectral-norm layer of a network in one launch per phase
+// (3 launches forward, 2 backward, instead of 3 and 3 per layer).
+//   job (10 x 64-bit words): W, u, v, sigma, t (scratch [K]), s (scratch [R]), R, K, dWsn, dW
+//   maps: (job, chunk) pairs per block; cols: 64 columns of W per block; rows: 4 rows per block;
+//   dot: one of SN_DOT_PARTS slices of R*K per block; apply: 2048 elements per block
+// ---------------------------------------------------------------------------
+#define SN_JOB_WORDS 10
+#define SN_DOT_PARTS 64
+__global__ __launch_bounds__(256) void sn_jobs_wt_u_kernel(const long long* __restrict__ jobs,
+                                                           const int* __restrict__ map) {
+  const long long* J = jobs + (long long)map[2 * blockIdx.x] * SN_JOB_WORDS;
+  const float* Wm = (const float*)J[0];
+  const float* u = (const float*)J[1];
+  float* t = (float*)J[4];
+  const int R = (int)J[6], K = (int)J[7];
+  __shared__ float sh[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int k = map[2 * blockIdx.x + 1] * 64 + lane;
+  float acc = 0.f;
+  if (k < K) {
+#pragma unroll 8
+    for (int r = w; r < R; r += 4) acc += Wm[(long long)r * K + k] * u[r];
+  }
+  sh[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && k < K) t[k] = sh[0][lane] + sh[1][lane] + sh[2][lane] + sh[3][lane];
+}
+__global__ __launch_bounds__(256) void sn_jobs_w_v_kernel(const long long* __restrict__ jobs,
+                                                          const int* __restrict__ map, int power_iter) {
+  const long long* J = jobs + (long long)map[2 * blockIdx.x] * SN_JOB_WORDS;
+  const float* Wm = (const float*)J[0];
+  const float* t = power_iter ? (const float*)J[4] : (const float*)J[2];
+  float* s = (float*)J[5];
+  const int R = (int)J[6], K = (int)J[7];
+  const int lane = threadIdx.x & 63;
+  const int r = map[2 * blockIdx.x + 1] * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  float acc = 0.f;
+#pragma unroll 4
+  for (int k = lane; k < K; k += 64) acc += Wm[(long long)r * K + k] * t[k];
+  acc = wave_sum(acc);
+  if (lane == 0) s[r] = acc;
+}
+__global__ __launch_bounds__(256) void sn_jobs_finish_kernel(const long long* __restrict__ jobs, float eps,
+                                                             int power_iter) {
+  const long long* J = jobs + (long long)blockIdx.x * SN_JOB_WORDS;
+  float* u = (float*)J[1];
+  float* v = (float*)J[2];
+  float* sigma = (float*)J[3];
+  const float* t = (const float*)J[4];
+  const float* s = (const float*)J[5];
+  const int R = (int)J[6], K = (int)J[7];
+  __shared__ float sh[4];
+  if (power_iter) {
+    float a = 0.f, b = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) a += t[k] * t[k];
+    for (int r = threadIdx.x; r < R; r += blockDim.x) b += s[r] * s[r];
+    float n2t = block_sum_256(a, sh);
+    float n2s = block_sum_256(b, sh);
+    float nt = fmaxf(sqrtf(n2t), eps);
+    float nwv = sqrtf(n2s) / nt;
+    float nu = fmaxf(nwv, eps);
+    for (int k = threadIdx.x; k < K; k += blockDim.x) v[k] = t[k] / nt;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) u[r] = (s[r] / nt) / nu;
+    if (threadIdx.x == 0) sigma[0] = nwv * nwv / nu;
+  } else {
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) acc += u[r] * s[r];
+    float d = block_sum_256(acc, sh);
+    if (threadIdx.x == 0) sigma[0] = d;
+  }
+}
+
+extern "C" int ried_sn_sigma_jobs(const long long* jobs, int njobs, const int* map_cols, int nblocks_cols,
+                                  const int* map_rows, int nblocks_rows, int power_iter, float eps,
+                                  hipStream_t stream) {
+  RIED_CHECK_ARG(jobs && njobs > 0 && map_cols && map_rows && nblocks_cols > 0 && nblocks_rows > 0,
+                 "ried_sn_sigma_jobs: bad arguments");
+  if (power_iter)
+    hipLaunchKernelGGL(sn_jobs_wt_u_kernel, dim3(nblocks_cols), dim3(256), 0, stream, jobs, map_cols);
+  hipLaunchKernelGGL(sn_jobs_w_v_kernel, dim3(nblocks_rows), dim3(256), 0, stream, jobs, map_rows, power_iter);
+  hipLaunchKernelGGL(sn_jobs_finish_kernel, dim3(njobs), dim3(256), 0, stream, jobs, eps, power_iter);
+  RIED_CHECK_LAUNCH("ried_sn_sigma_jobs");
+  return RIED_OK;
+}
+
+// partial[job][part] = sum over the part's slice of dWsn * W  (t, the [K] scratch, holds the SN_DOT_PARTS partials)
+__global__ __launch_bounds__(256) void sn_jobs_bwd_dot_kernel(const long long* __restrict__ jobs,
+                                                              const int* __restrict__ map) {
+  const long long* J = jobs + (long long)map[2 * blockIdx.x] * SN_JOB_WORDS;
+  const float* Wm = (const float*)J[0];
+  const float* dWsn = (const float*)J[8];
+  float* part = (float*)J[4];
+  const long long n = J[6] * J[7];
+  const int p = map[2 * blockIdx.x + 1];
+  const long long per = (n + SN_DOT_PARTS - 1) / SN_DOT_PARTS;
+  const long long lo = p * per, hi = lo + per < n ? lo + per : n;
+  __shared__ float sh[4];
+  float acc = 0.f;
+#pragma unroll 4
+  for (long long i = lo + threadIdx.x; i < hi; i += 256) acc += dWsn[i] * Wm[i];
+  float d = block_sum_256(acc, sh);
+  if (threadIdx.x == 0) part[p] = d;
+}
+__global__ __launch_bounds__(256) void sn_jobs_bwd_apply_kernel(const long long* __restrict__ jobs,
+                                                                const int* __restrict__ map, int accumulate) {
+  const long long* J = jobs + (long long)map[2 * blockIdx.x] * SN_JOB_WORDS;
+  const float* u = (const float*)J[1];
+  const float* v = (const float*)J[2];
+  const float* part = (const float*)J[4];
+  const float* dWsn = (const float*)J[8];
+  float* dW = (float*)J[9];
+  const int K = (int)J[7];
+  const long long n = J[6] * J[7];
+  __shared__ float sh[4];
+  float d = block_sum_256(threadIdx.x < SN_DOT_PARTS ? part[threadIdx.x] : 0.f, sh);
+  const float sg = ((const float*)J[3])[0];
+  const float coef = d / sg;
+  const long long i0 = (long long)map[2 * blockIdx.x + 1] * 2048 + threadIdx.x;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    long long i = i0 + q * 256;
+    if (i >= n) break;
+    int r = (int)(i / K), k = (int)(i - (long long)r * K);
+    float g = (dWsn[i] - coef * u[r] * v[k]) / sg;
+    dW[i] = accumulate ? dW[i] + g : g;
+  }
+}
+
+extern "C" int ried_sn_backward_jobs(const long long* jobs, const int* map_dot, int nblocks_dot, const int* map_apply,
+                                     int nblocks_apply, int accumulate, hipStream_t stream) {
+  RIED_CHECK_ARG(jobs && map_dot && map_apply && nblocks_dot > 0 && nblocks_apply > 0,
+                 "ried_sn_backward_jobs: bad arguments");
+  hipLaunchKernelGGL(sn_jobs_bwd_dot_kernel, dim3(nblocks_dot), dim3(256), 0, stream, jobs, map_dot);
+  hipLaunchKernelGGL(sn_jobs_bwd_apply_kernel, dim3(nblocks_apply), dim3(256), 0, stream, jobs, map_apply, accumulate);
+  RIED_CHECK_LAUNCH("ried_sn_backward_jobs");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
 // perceptual-loss tap: loss[0] += loss_scale * sum (a-b)^2 ;  g (+)= grad_scale * (a-b)
 // a = features of the prediction, b = features of the target (src/loss.py:184-189)
 // ---------------------------------------------------------------------------

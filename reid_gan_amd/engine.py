@@ -128,6 +128,7 @@ class Ctx:
         self.build_lane = 0                # lane (stream + scratch set) the layers being built will run on
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
         self.wreds = ops.JobTable(11)      # every weight-gradient slab reduction: one launch (end_backward)
+        self.sn = ops.SnJobs()             # every spectral-norm layer: power iteration / sigma gradient per launch
         self._wred_slab: List[Tuple[int, int]] = []      # (job, slab offset) patched once the arena exists
 
     # activations
@@ -186,6 +187,7 @@ class Ctx:
             self.wreds.rows[j][0] = self.slab.data_ptr() + 4 * off
         self.packs.finalize(dev)
         self.wreds.finalize(dev)
+        self.sn.finalize(dev)
         # one scratch set per lane: branches of a Par run concurrently on their own streams
         self.tmps = [torch.empty(max(self.tmp_elems, 8), dtype=torch.bfloat16, device=dev) for _ in range(N_LANES)]
         self.f32s = [torch.empty(max(self.f32_elems, 4), dtype=F32, device=dev) for _ in range(N_LANES)]
@@ -210,12 +212,24 @@ class Ctx:
         if not self.chain:       # a chain plan overwrites every gradient buffer before reading it
             self.grad_arena.zero_()
 
+    def sn_sigmas(self):
+        """One power iteration (training) and sigma = u^T W v for every spectral-norm layer; must precede
+        pack_all(), which divides the packed weights by sigma."""
+        if self.sn.jobs is not None:
+            ops.sn_sigma_jobs(self.sn, power_iter=self.training)
+
+    def sn_finish_wgrads(self):
+        """After end_backward(): gradients w.r.t. W/sigma (each layer's dwsn) -> gradients of weight_orig."""
+        if self.sn.jobs is not None:
+            ops.sn_backward_jobs(self.sn)
+
     def end_backward(self):
         """Reduce the weight-gradient slabs of every layer into the master gradients (one launch)."""
         ops.wgrad_reduce_jobs(self.wreds)
 
 
 N_LANES = 4
+FUSE_MAX_ROWS = int(os.environ.get("RIED_FUSE_MAX_ROWS", "0"))   # measured: the separate finalize launch is faster (0 = never fuse)
 _side_streams: List["torch.cuda.Stream"] = []
 
 
@@ -370,6 +384,7 @@ class ConvBN:
         self.out, self.accumulate = out, accumulate
         self.raw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
+        self.counters = torch.zeros(2, dtype=torch.int32, device=ctx.device)    # last-block tickets: fwd, bwd
         self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, c.cout, c.sh, c.sw, deconv)
         ctx.stats(self, "stats", self.stat_rows * 2 * cout)
         if ctx.grads:
@@ -378,7 +393,12 @@ class ConvBN:
 
     def forward(self):
         ctx, c, st = self.ctx, self.core, self.ctx.st
-        if ctx.training:
+        if ctx.training and self.stat_rows <= FUSE_MAX_ROWS:
+            # few partial rows: the conv's last block reduces them itself (one dependent launch fewer)
+            ops.conv2d_bn(c.xin.v, c.wp, self.raw, c.kh, c.kw, c.sh, c.sw, c.ph, c.pw, self.stats, self.counters[0:],
+                          self.save, st.b[self.bn + ".running_mean"], st.b[self.bn + ".running_var"],
+                          st.b[self.bn + ".num_batches_tracked"], transposed=c.deconv)
+        elif ctx.training:
             c.conv(self.raw, stats=self.stats)
             ops.bn_finalize(self.stats, self.stat_rows, c.cout, self.raw.npix, self.save,
                             st.b[self.bn + ".running_mean"],
@@ -399,7 +419,8 @@ class ConvBN:
         ctx, c, st = self.ctx, self.core, self.ctx.st
         draw = ctx.tmp_view(c.N, c.Ho, c.Wo, c.cout, self.lane)
         ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
-                        ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True)
+                        ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True,
+                        counter=self.counters[1:] if self.raw.npix * c.cout <= FUSE_MAX_ROWS * 8192 else None)
         c.wgrad(draw)
 
     def backward_input(self):
@@ -793,7 +814,6 @@ class SNConv:
         dev = ctx.device
         self.K = cin * 9
         self.sigma = torch.ones(1, dtype=F32, device=dev)
-        self.scratch = torch.zeros(self.K + cout + 2, dtype=F32, device=dev)    # sn_sigma: [K + R]; sn_backward: [1]
         N, Ho, Wo, _ = out.shape
         self.dwsn = torch.empty(cout * self.K, dtype=F32, device=dev) if ctx.grads else None
         if not first:
@@ -808,13 +828,10 @@ class SNConv:
             if not first and xin.act.fuse_slope is not None:
                 _, H, W, _ = xin.shape
                 xin.act.fused = _Fused(ctx, N, H, W, cin, stride, stride)
+        st = ctx.st
+        ctx.sn.add(st.p[prefix + ".weight_orig"], st.b[prefix + ".weight_u"], st.b[prefix + ".weight_v"], self.sigma,
+                   cout, self.K, self.dwsn, st.g[prefix + ".weight_orig"] if ctx.grads else None)
         self.x_img: Optional[torch.Tensor] = None
-
-    def compute_sigma(self):
-        """One power iteration (training) and sigma = u^T W v; must precede Ctx.pack_all(), which divides by it."""
-        st, p = self.ctx.st, self.prefix
-        ops.sn_sigma(st.p[p + ".weight_orig"], self.cout, self.K, st.b[p + ".weight_u"], st.b[p + ".weight_v"],
-                     self.sigma, self.scratch, power_iter=self.ctx.training)
 
     def forward(self, x_img: Optional[torch.Tensor] = None):
         st, p = self.ctx.st, self.prefix
@@ -858,12 +875,6 @@ class SNConv:
                                 stats=xf.stats if wgrad else None, stats_post=True)
             else:
                 self.core.dgrad(dpre, xin.g, accumulate=False)
-
-    def finish_wgrad(self):
-        """After Ctx.end_backward(): gradient of W/sigma (in dwsn) -> gradient of weight_orig."""
-        st, p = self.ctx.st, self.prefix
-        ops.sn_backward(self.dwsn, st.p[p + ".weight_orig"], st.b[p + ".weight_u"], st.b[p + ".weight_v"],
-                        self.sigma, self.cout, self.K, st.g[p + ".weight_orig"], self.scratch)
 
 
 class Attn:
@@ -996,9 +1007,7 @@ class Discriminator:
     def forward(self, x_img: torch.Tensor) -> Slot:
         """x_img: fp32 (N,1,H,W).  Returns the last activation (N, H/16, W/16, 512) NHWC bf16."""
         assert x_img.shape == (self.N, 1, self.H, self.W) and x_img.dtype == F32 and x_img.is_contiguous()
-        for l in self.layers:
-            if isinstance(l, SNConv):
-                l.compute_sigma()
+        self.ctx.sn_sigmas()
         self.ctx.begin_forward()
         for i, l in enumerate(self.layers):
             if i == 0:
@@ -1017,9 +1026,7 @@ class Discriminator:
                 l.backward(n0, n1, wgrad)
         if wgrad:
             self.ctx.end_backward()
-            for l in self.layers:
-                if isinstance(l, SNConv):
-                    l.finish_wgrad()
+            self.ctx.sn_finish_wgrads()
 
     def output_nchw(self) -> torch.Tensor:
         """(N, 8192-like) fp32 in the reference's flattening order (C, H, W) (src/rinet.py:31)."""

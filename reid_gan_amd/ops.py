@@ -147,6 +147,45 @@ def wgrad_reduce_jobs(t: JobTable):
         lib.ried_wgrad_reduce_jobs(_p(t.jobs), _p(t.blockmap), t.nblocks, _stream())
 
 
+class SnJobs:
+    """All spectral-norm layers of a network: one job row per layer and the block maps of the five kernels."""
+
+    def __init__(self):
+        self.rows, self.keep = [], []
+        self.jobs = None
+
+    def add(self, W, u, v, sigma, R, K, dWsn=None, dW=None):
+        dev = W.device
+        t = torch.empty(max(K, 64), dtype=torch.float32, device=dev)
+        s = torch.empty(R, dtype=torch.float32, device=dev)
+        self.keep += [t, s]
+        self.rows.append([W.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(), t.data_ptr(), s.data_ptr(), R, K,
+                          0 if dWsn is None else dWsn.data_ptr(), 0 if dW is None else dW.data_ptr()])
+
+    def finalize(self, device):
+        import numpy as np
+        if not self.rows:
+            return
+        def bmap(count):
+            m = [(j, c) for j, r in enumerate(self.rows) for c in range(count(r[6], r[7]))]
+            return torch.from_numpy(np.asarray(m, dtype=np.int32).reshape(-1)).to(device), len(m)
+        self.jobs = torch.from_numpy(np.asarray(self.rows, dtype=np.int64)).to(device)
+        self.map_cols, self.n_cols = bmap(lambda R, K: (K + 63) // 64)
+        self.map_rows, self.n_rows = bmap(lambda R, K: (R + 3) // 4)
+        self.map_dot, self.n_dot = bmap(lambda R, K: 64)
+        self.map_apply, self.n_apply = bmap(lambda R, K: (R * K + 2047) // 2048)
+
+
+def sn_sigma_jobs(j: SnJobs, power_iter=True, eps=1e-12):
+    lib.ried_sn_sigma_jobs(_p(j.jobs), len(j.rows), _p(j.map_cols), j.n_cols, _p(j.map_rows), j.n_rows,
+                           int(power_iter), eps, _stream())
+
+
+def sn_backward_jobs(j: SnJobs, accumulate=False):
+    lib.ried_sn_backward_jobs(_p(j.jobs), _p(j.map_dot), j.n_dot, _p(j.map_apply), j.n_apply, int(accumulate),
+                              _stream())
+
+
 # --------------------------------------------------------------------------- batch norm
 def conv2d_stat_rows(nimg, Ho, Wo, Cout, sh=1, sw=1, transposed=False) -> int:
     return lib.ried_conv2d_stat_rows(nimg, Ho, Wo, Cout, sh, sw, int(transposed))
@@ -178,10 +217,19 @@ def bn_apply(x: View, y: View, save, gamma, beta, relu=True, accumulate=False):
 
 
 def bn_backward(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma=None, dbeta=None, relu=True,
-                accumulate=False):
-    """scratch: fp32, at least bn_backward_scratch_floats(C) elements."""
+                accumulate=False, counter: Optional[torch.Tensor] = None):
+    """scratch: fp32, at least bn_backward_scratch_floats(C) elements.  counter: a zeroed int32 element owned by
+    the layer; with it the reduction's last block finishes the sums (one launch fewer)."""
     lib.ried_bn_backward(dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta),
-                         int(relu), _p(scratch), _p(dgamma), _p(dbeta), int(accumulate), _stream())
+                         int(relu), _p(scratch), _p(dgamma), _p(dbeta), int(accumulate), _p(counter), _stream())
+
+
+def conv2d_bn(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, stats, counter, save, rm=None, rv=None,
+              nbt=None, transposed=False, eps=1e-5, momentum=0.1):
+    """Convolution + train-mode BatchNorm statistics in one launch (y = raw conv result, save = mean / invstd)."""
+    lib.ried_conv2d_bn(x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C, kh, kw, sh, sw, ph, pw,
+                       int(transposed), _p(stats), _p(counter), eps, momentum, _p(save), _p(rm), _p(rv), _p(nbt),
+                       _stream())
 
 
 # --------------------------------------------------------------------------- pooling etc.

@@ -350,7 +350,7 @@ class _SNRunner:
 
     def forward(self, x):
         x = x.contiguous().to(F32)
-        self.layer.compute_sigma()
+        self.ctx.sn_sigmas()
         self.ctx.begin_forward()
         if self.first:
             self.x = x
@@ -368,11 +368,11 @@ class _SNRunner:
         if self.first:
             self.dx.zero_()
             self.layer.backward(0, self.N, True, self.dx if need_dx else None)
-            self.layer.finish_wgrad()
+            self.ctx.sn_finish_wgrads()
             return self.dx.clone() if need_dx else None
         self.layer.backward(0, self.N, True)
         self.ctx.end_backward()
-        self.layer.finish_wgrad()
+        self.ctx.sn_finish_wgrads()
         if not need_dx:
             return None
         ops.nhwc_to_nchw(self.a_in.g, self.dx)

@@ -81,6 +81,23 @@ def test_conv2d_forward_stats(cin, cout, k, s, p, H):
     ops.bn_finalize(stats, rows, cout, ref.numel() // cout, save)
     close(save[0].cpu(), ref.mean((0, 2, 3)), 3e-3 * 10, "mean")
     close(save[1].cpu(), torch.rsqrt(ref.var((0, 2, 3), unbiased=False) + 1e-5), 3e-3, "invstd")
+    # the fused form: the conv's last block finalizes; twice, to see the ticket counter return to zero
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    rm, rv = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+    nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for it in range(2):
+        save2 = torch.full((2, cout), float("nan"), device=DEV)
+        y2 = ops.new_view(3, Ho, Wo, cout)
+        ops.conv2d_bn(xv, pack(w), y2, k[0], k[1], s, s, p[0], p[1], stats, counter, save2, rm, rv, nbt)
+        torch.cuda.synchronize()
+        assert counter.item() == 0 and nbt.item() == it + 1
+        close(from_view(y2), ref, what="y (fused)")
+        close(save2[0].cpu(), save[0].cpu(), 1e-5, "mean (fused)")
+        close(save2[1].cpu(), save[1].cpu(), 1e-5, "invstd (fused)")
+    n = ref.numel() // cout
+    m, v = ref.mean((0, 2, 3)), ref.var((0, 2, 3), unbiased=False) * n / (n - 1)
+    close(rm.cpu(), 0.19 * m, 3e-2, "running mean after two steps")
+    close(rv.cpu(), 0.81 + 0.19 * v, 3e-3, "running var after two steps")
 
 
 def test_conv2d_bias_act_slice_accumulate():
@@ -300,6 +317,16 @@ def test_bn_forward_backward():
     close(from_view(dxv), xr.grad, what="dx")
     close(dg.cpu(), g2.grad, 5e-3, "dgamma")
     close(db.cpu(), b2.grad, 5e-3, "dbeta")
+    # with a ticket counter the reduction's last block finishes the sums: same results, counter back at zero
+    counter = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for _ in range(2):
+        dx2 = ops.new_view(N, H, H, C)
+        dg2, db2 = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        scratch.fill_(float("nan"))
+        ops.bn_backward(to_view(dy), xv, dx2, save, gamma.to(DEV), beta.to(DEV), scratch, dg2, db2, counter=counter)
+        torch.cuda.synchronize()
+        assert counter.item() == 0
+        assert torch.equal(dx2.torch(), dxv.torch()) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
@@ -458,6 +485,41 @@ def test_spectral_norm_sigma_and_backward():
     dW = torch.zeros(R, K, device=DEV)
     ops.sn_backward(dWsn.to(DEV), Wm.to(DEV), ud, vd, sg, R, K, dW, scratch[:1])
     close(dW.cpu(), Wr.grad, 1e-4, "dW")
+
+
+def test_spectral_norm_job_tables_match_single_layer_calls():
+    """All layers in one launch per phase = the per-layer entry points (same arithmetic; summation order of the
+    sigma-gradient dot differs: 1e-5)."""
+    g = torch.Generator().manual_seed(9)
+    jobs = ops.SnJobs()
+    ref = []
+    for R, K in [(64, 9), (128, 576), (512, 4608), (40, 72)]:
+        W = torch.randn(R, K, generator=g).to(DEV) * K ** -0.5
+        u = torch.nn.functional.normalize(torch.randn(R, generator=g), dim=0).to(DEV)
+        v = torch.nn.functional.normalize(torch.randn(K, generator=g), dim=0).to(DEV)
+        dWsn = torch.randn(R, K, generator=g).to(DEV)
+        u1, v1, s1 = u.clone(), v.clone(), torch.zeros(1, device=DEV)
+        scratch = torch.zeros(K + R + 2, device=DEV)
+        ops.sn_sigma(W, R, K, u1, v1, s1, scratch, True)
+        dW1 = torch.zeros(R, K, device=DEV)
+        ops.sn_backward(dWsn, W, u1, v1, s1, R, K, dW1, scratch[:1])
+        s0 = torch.zeros(1, device=DEV)
+        ops.sn_sigma(W, R, K, u1.clone(), v1.clone(), s0, scratch, False)     # sigma with the stored u, v
+        u2, v2, s2, dW2 = u.clone(), v.clone(), torch.zeros(1, device=DEV), torch.full((R, K), 3.0, device=DEV)
+        jobs.add(W, u2, v2, s2, R, K, dWsn, dW2)
+        jobs.keep += [W, dWsn]                                   # the table holds raw addresses only
+        ref.append((u1, v1, s1, dW1, s0, u2, v2, s2, dW2))
+    jobs.finalize(DEV)
+    ops.sn_sigma_jobs(jobs, power_iter=True)
+    ops.sn_backward_jobs(jobs)
+    torch.cuda.synchronize()
+    for u1, v1, s1, dW1, s0, u2, v2, s2, dW2 in ref:
+        close(u2.cpu(), u1.cpu(), 1e-6, "u"); close(v2.cpu(), v1.cpu(), 1e-6, "v"); close(s2.cpu(), s1.cpu(), 1e-6, "sigma")
+        close(dW2.cpu(), dW1.cpu(), 1e-5, "dW")
+    ops.sn_sigma_jobs(jobs, power_iter=False)
+    torch.cuda.synchronize()
+    for u1, v1, s1, dW1, s0, u2, v2, s2, dW2 in ref:
+        close(s2.cpu(), s0.cpu(), 1e-6, "sigma without power iteration")
 
 
 def test_mse_tap_and_loss_scalars():
