@@ -814,14 +814,16 @@ __global__ void colsum_finish_kernel(const float* __restrict__ part, int nrows, 
   }
 }
 
+#define ROWSUM_ROWS_PER_BLOCK 1024
 __global__ __launch_bounds__(ROWRED_THREADS) void stat_rows_sum_kernel(const float* __restrict__ part, int nrows,
                                                                        int C, float* __restrict__ out) {
   __shared__ float sh[32][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
+  const int r0 = blockIdx.y * ROWSUM_ROWS_PER_BLOCK, r1 = min(nrows, r0 + ROWSUM_ROWS_PER_BLOCK);
   float a = 0.f;
   if (c < C) {
 #pragma unroll 4
-    for (int r = ty; r < nrows; r += 32) a += part[(long long)r * 2 * C + c];
+    for (int r = r0 + ty; r < r1; r += 32) a += part[(long long)r * 2 * C + c];
   }
   sh[ty][threadIdx.x & 31] = a;
   __syncthreads();
@@ -829,14 +831,15 @@ __global__ __launch_bounds__(ROWRED_THREADS) void stat_rows_sum_kernel(const flo
     float t = 0.f;
 #pragma unroll
     for (int k = 0; k < 32; ++k) t += sh[k][threadIdx.x & 31];
-    out[c] += t;
+    if (gridDim.y == 1) out[c] += t;
+    else atomicAdd(&out[c], t);           // a handful of adders per address
   }
 }
 // out[c] += sum_r stats[r][0][c]; stats: [nrows][2][C] partial rows written by a conv epilogue
 extern "C" int ried_stat_rows_sum(const float* stats, int nrows, int C, float* out, hipStream_t stream) {
   RIED_CHECK_ARG(stats && out && nrows > 0 && C > 0, "ried_stat_rows_sum: bad arguments");
-  hipLaunchKernelGGL(stat_rows_sum_kernel, dim3(ceil_div(C, 32)), dim3(ROWRED_THREADS), 0, stream, stats, nrows, C,
-                     out);
+  hipLaunchKernelGGL(stat_rows_sum_kernel, dim3(ceil_div(C, 32), ceil_div(nrows, ROWSUM_ROWS_PER_BLOCK)),
+                     dim3(ROWRED_THREADS), 0, stream, stats, nrows, C, out);
   RIED_CHECK_LAUNCH("ried_stat_rows_sum");
   return RIED_OK;
 }
@@ -910,28 +913,39 @@ extern "C" int ried_softmax_bwd(const float* dP, const void* P, void* dS, long l
 // dot / sums to device scalars
 // ---------------------------------------------------------------------------
 // out[0] += scale * sum_{p,c} a*b   (b may be null: plain sum of a)
-__global__ void dot_kernel(const bf16_t* __restrict__ a, long long lda, const bf16_t* __restrict__ b, long long ldb,
-                           long long npix, int C, float scale, float* __restrict__ out) {
-  __shared__ float sh[4];
-  const int CC = C >> 3;
-  long long total = npix * CC;
+// Few, large blocks: each block ends in one atomic add on the same address, and those serialise.
+#define DOT_THREADS 1024
+__global__ __launch_bounds__(DOT_THREADS) void dot_kernel(const bf16_t* __restrict__ a, long long lda,
+                                                          const bf16_t* __restrict__ b, long long ldb, long long npix,
+                                                          int C, float scale, float* __restrict__ out) {
+  __shared__ float sh[DOT_THREADS / 64];
+  ChanWalk w(C);
   float acc = 0.f;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    long long p = i / CC;
-    int c = (int)(i - p * CC) << 3;
-    float fa[8], fb[8];
-    unpack8(ld8(a + p * lda + c), fa);
-    if (b) {
-      unpack8(ld8(b + p * ldb + c), fb);
+  if (w.active) {
+    const int c = w.c;
+#pragma unroll 4
+    for (long long p = w.p; p < npix; p += w.step) {
+      float fa[8], fb[8];
+      unpack8(ld8(a + p * lda + c), fa);
+      if (b) {
+        unpack8(ld8(b + p * ldb + c), fb);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc += fa[q] * fb[q];
-    } else {
+        for (int q = 0; q < 8; ++q) acc += fa[q] * fb[q];
+      } else {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc += fa[q];
+        for (int q = 0; q < 8; ++q) acc += fa[q];
+      }
     }
   }
-  float t = block_sum_256(acc, sh);
-  if (threadIdx.x == 0) atomicAdd(out, t * scale);
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < DOT_THREADS / 64; ++k) t += sh[k];
+    atomicAdd(out, t * scale);
+  }
 }
 
 extern "C" int ried_dot(const void* a, long long lda, const void* b, long long ldb, long long npix, int C, float scale,
@@ -939,7 +953,8 @@ extern "C" int ried_dot(const void* a, long long lda, const void* b, long long l
   CHECK_VIEW("ried_dot", a, lda, C);
   if (b) CHECK_VIEW("ried_dot", b, ldb, C);
   RIED_CHECK_ARG(out && npix > 0, "ried_dot: bad arguments");
-  hipLaunchKernelGGL(dot_kernel, dim3(ew_grid(npix * (C / 8), EW_THREADS * 4, 128)), dim3(EW_THREADS), 0, stream,
+  RIED_CHECK_ARG(C <= 8 * DOT_THREADS, "ried_dot: C too large");
+  hipLaunchKernelGGL(dot_kernel, dim3(ew_grid(npix, (DOT_THREADS / (C / 8)) * 8, 128)), dim3(DOT_THREADS), 0, stream,
                      (const bf16_t*)a, lda, (const bf16_t*)b, ldb, npix, C, scale, out);
   RIED_CHECK_LAUNCH("ried_dot");
   return RIED_OK;

@@ -18,95 +18,99 @@ __device__ __forceinline__ void unpack8s(const u32x4& v, float (&f)[8]) {
 // 3x3, pad 1, one input channel (fp32 image), stride 1 or 2
 // ---------------------------------------------------------------------------
 // y[p][co] = act( sum_t w[co][t] * (xin*in_scale + in_shift)[p@t] / sigma + bias[co] ), zero padding after the affine.
-// A thread owns 8 output channels (its 72 weights live in registers) and walks pixels p, p + step, ...; the pixel
-// coordinates advance by a precomputed mixed-radix step, so the loop has no integer division.
-struct PixelWalk {
-  int n, y, x;        // current (image, row, column)
-  int dn, dy, dx;     // step, as whole images + rows + columns
-  int Ho, Wo;
-  __device__ __forceinline__ void init(long long p, long long step, int Ho_, int Wo_) {
-    Ho = Ho_; Wo = Wo_;
-    long long hw = (long long)Ho * Wo;
-    n = (int)(p / hw); int r = (int)(p - (long long)n * hw); y = r / Wo; x = r - y * Wo;
-    dn = (int)(step / hw); int r2 = (int)(step - (long long)dn * hw); dy = r2 / Wo; dx = r2 - dy * Wo;
+//
+// One lane per output pixel: a block takes 256 consecutive pixels, each lane reads its 9 input values once
+// (neighbouring lanes read neighbouring addresses) and produces all COUT channels from weights that are uniform
+// across the wave (LDS broadcast reads).  The bf16 results go through a padded LDS tile so that the global stores
+// are full 16-byte chunks in linear order instead of 64 scattered rows per instruction.
+#define C1_TILE 256
+__device__ __forceinline__ void c1_taps(const float* __restrict__ x, long long p, long long npix, int H, int W, int Ho,
+                                        int Wo, int stride, float in_scale, float in_shift, float (&xv)[9]) {
+#pragma unroll
+  for (int t = 0; t < 9; ++t) xv[t] = 0.f;
+  if (p >= npix) return;
+  const long long hw = (long long)Ho * Wo;
+  const int n = (int)(p / hw);
+  const int r0 = (int)(p - (long long)n * hw);
+  const int oy = r0 / Wo, ox = r0 - oy * Wo;
+  const float* xi = x + (long long)n * H * W;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    int hi = oy * stride - 1 + r;
+#pragma unroll
+    for (int z = 0; z < 3; ++z) {
+      int wi = ox * stride - 1 + z;
+      bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+      int off = ok ? hi * W + wi : 0;
+      float v = xi[off] * in_scale + in_shift;
+      xv[r * 3 + z] = ok ? v : 0.f;
+    }
   }
-  __device__ __forceinline__ void next() {
-    x += dx; y += dy; n += dn;
-    if (x >= Wo) { x -= Wo; ++y; }
-    if (y >= Ho) { y -= Ho; ++n; }
-  }
-};
+}
 
 template <int COUT>
-__global__ __launch_bounds__(SP_THREADS) void conv_c1_fwd_kernel(
+__global__ __launch_bounds__(C1_TILE) void conv_c1_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sigma,
     const float* __restrict__ bias, bf16_t* __restrict__ y, long long ldy, int nimg, int H, int W, int Ho, int Wo,
     int stride, float in_scale, float in_shift, int act, float* __restrict__ stats) {
+  constexpr int ROWB = COUT * 2 + 16;                 // bytes per pixel in the LDS tile (16 of padding)
   constexpr int CC = COUT / 8;
-  constexpr int PPB = SP_THREADS / CC;              // pixels per block pass
-  __shared__ float lst[2][COUT];
+  __shared__ __attribute__((aligned(16))) char tile[C1_TILE * ROWB];
+  __shared__ __attribute__((aligned(16))) float wl[9 * COUT + COUT];     // [t][co] / sigma, then bias
+  __shared__ float red[4][2 * COUT];
   const float inv = sigma ? 1.f / sigma[0] : 1.f;
-  if (stats) for (int i = threadIdx.x; i < 2 * COUT; i += SP_THREADS) (&lst[0][0])[i] = 0.f;
-  __syncthreads();
-  const int c = (threadIdx.x % CC) * 8;
-  const int pl = threadIdx.x / CC;
-  float wr[9][8], bq[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    bq[q] = bias ? bias[c + q] : 0.f;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wr[t][q] = w[(c + q) * 9 + t] * inv;
+  for (int i = threadIdx.x; i < 9 * COUT; i += C1_TILE) {
+    int t = i / COUT, co = i - t * COUT;
+    wl[i] = w[co * 9 + t] * inv;
   }
+  for (int i = threadIdx.x; i < COUT; i += C1_TILE) wl[9 * COUT + i] = bias ? bias[i] : 0.f;
   const long long npix = (long long)nimg * Ho * Wo;
-  const long long step = (long long)gridDim.x * PPB;
-  float s1[8], s2[8];
+  const long long p0 = (long long)blockIdx.x * C1_TILE;
+  float xv[9];
+  c1_taps(x, p0 + threadIdx.x, npix, H, W, Ho, Wo, stride, in_scale, in_shift, xv);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
-  long long p = (long long)blockIdx.x * PPB + pl;
-  PixelWalk pw;
-  pw.init(p, step, Ho, Wo);
-  for (; p < npix; p += step, pw.next()) {
+  for (int cc = 0; cc < CC; ++cc) {
     float acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) acc[q] = 0.f;
-    const float* xi = x + (long long)pw.n * H * W;
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      int hi = pw.y * stride - 1 + r;
-#pragma unroll
-      for (int z = 0; z < 3; ++z) {
-        int wi = pw.x * stride - 1 + z;
-        bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-        float v = ok ? xi[(long long)hi * W + wi] * in_scale + in_shift : 0.f;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += v * wr[r * 3 + z][q];
-      }
+    for (int t = 0; t < 9; ++t) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wl[t * COUT + cc * 8]);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wl[t * COUT + cc * 8 + 4]);
+      acc[0] += xv[t] * w0[0]; acc[1] += xv[t] * w0[1]; acc[2] += xv[t] * w0[2]; acc[3] += xv[t] * w0[3];
+      acc[4] += xv[t] * w1[0]; acc[5] += xv[t] * w1[1]; acc[6] += xv[t] * w1[2]; acc[7] += xv[t] * w1[3];
     }
-    if (stats) {
+    if (stats) {      // per-channel sum and sum of squares of the raw results over the block's pixels
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { s1[q] += acc[q]; s2[q] += acc[q] * acc[q]; }
+      for (int q = 0; q < 8; ++q) {
+        float s1 = wave_sum(acc[q]), s2 = wave_sum(acc[q] * acc[q]);      // out-of-range pixels hold zeros
+        if (lane == 0) { red[wave][cc * 8 + q] = s1; red[wave][COUT + cc * 8 + q] = s2; }
+      }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = acc[q] + bq[q];
+      float v = acc[q] + wl[9 * COUT + cc * 8 + q];
       if (act == 1) v = fmaxf(v, 0.f);
       else if (act == 2) v = v > 0.f ? v : 0.2f * v;
       acc[q] = v;
     }
-    *reinterpret_cast<u32x4*>(y + p * ldy + c) =
+    *reinterpret_cast<u32x4*>(tile + threadIdx.x * ROWB + cc * 16) =
         u32x4{pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
   }
-  if (stats) {
+  __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { atomicAdd(&lst[0][c + q], s1[q]); atomicAdd(&lst[1][c + q], s2[q]); }
-    __syncthreads();
-    float* row = stats + (long long)blockIdx.x * 2 * COUT;        // one partial row per block (no global atomics)
-    for (int i = threadIdx.x; i < 2 * COUT; i += SP_THREADS) row[i] = (&lst[0][0])[i];
+  for (int i = 0; i < CC; ++i) {
+    int j = i * C1_TILE + threadIdx.x;
+    int px = j / CC, cc = j - px * CC;
+    if (p0 + px < npix)
+      *reinterpret_cast<u32x4*>(y + (p0 + px) * ldy + cc * 8) = *reinterpret_cast<const u32x4*>(tile + px * ROWB + cc * 16);
   }
-}
-
-static int c1_fwd_grid(long long npix, int Cout, bool stats) {
-  return ew_grid(npix, (SP_THREADS / (Cout / 8)) * 2, stats ? 1024 : 4096);
+  if (stats) {
+    float* row = stats + (long long)blockIdx.x * 2 * COUT;        // one partial row per block (no global atomics)
+    for (int i = threadIdx.x; i < 2 * COUT; i += C1_TILE) row[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+  }
 }
 
 extern "C" int ried_conv_c1_fwd(const float* x, const float* w, const float* sigma, const float* bias, void* y,
@@ -116,14 +120,15 @@ extern "C" int ried_conv_c1_fwd(const float* x, const float* w, const float* sig
   RIED_CHECK_ARG(stride == 1 || stride == 2, "ried_conv_c1_fwd: stride must be 1 or 2");
   RIED_CHECK_ARG(ldy % 8 == 0 && ldy >= Cout && ((uintptr_t)y % 16) == 0, "ried_conv_c1_fwd: output view");
   RIED_CHECK_ARG(Cout == 32 || Cout == 64, "ried_conv_c1_fwd: Cout must be 32 or 64 (got %d)", Cout);
+  RIED_CHECK_ARG((long long)H * W < (1ll << 31), "ried_conv_c1_fwd: image too large");
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   long long npix = (long long)nimg * Ho * Wo;
-  int grid = c1_fwd_grid(npix, Cout, stats != nullptr);
+  int grid = ceil_div(npix, C1_TILE);
   if (Cout == 32)
-    hipLaunchKernelGGL(conv_c1_fwd_kernel<32>, dim3(grid), dim3(SP_THREADS), 0, stream, x, w, sigma, bias,
+    hipLaunchKernelGGL(conv_c1_fwd_kernel<32>, dim3(grid), dim3(C1_TILE), 0, stream, x, w, sigma, bias,
                        (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats);
   else
-    hipLaunchKernelGGL(conv_c1_fwd_kernel<64>, dim3(grid), dim3(SP_THREADS), 0, stream, x, w, sigma, bias,
+    hipLaunchKernelGGL(conv_c1_fwd_kernel<64>, dim3(grid), dim3(C1_TILE), 0, stream, x, w, sigma, bias,
                        (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats);
   RIED_CHECK_LAUNCH("ried_conv_c1_fwd");
   return RIED_OK;
@@ -132,58 +137,75 @@ extern "C" int ried_conv_c1_fwd(const float* x, const float* w, const float* sig
 // rows of the partial-statistics buffer ([rows][2][Cout]) that ried_conv_c1_fwd writes when stats is given
 extern "C" int ried_conv_c1_stat_rows(int nimg, int H, int W, int Cout, int stride) {
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
-  return c1_fwd_grid((long long)nimg * Ho * Wo, Cout, true);
+  return ceil_div((long long)nimg * Ho * Wo, C1_TILE);
 }
 
-// part[block][co][t] = sum over the block's pixels of dy[p][co] * xaff[p@t]; a second kernel adds the rows into dw
+// part[block][co][t] = sum over the block's pixels of dy[p][co] * xaff[p@t]; a second kernel adds the rows into dw.
+// Tiles of 256 pixels: the dy tile is staged through LDS with coalesced 16-byte loads and each thread computes the
+// 9 taps of one pixel; then wave w accumulates channels [w*COUT/4, (w+1)*COUT/4) for all 256 pixels, one pixel
+// per lane and pass, in registers.  The lanes are summed once, after the block's last tile.
 template <int COUT>
-__global__ __launch_bounds__(SP_THREADS) void conv_c1_wgrad_kernel(const float* __restrict__ x,
-                                                                   const bf16_t* __restrict__ dy, long long lddy,
-                                                                   int nimg, int H, int W, int Ho, int Wo, int stride,
-                                                                   float in_scale, float in_shift,
-                                                                   float* __restrict__ part) {
+__global__ __launch_bounds__(C1_TILE) void conv_c1_wgrad_kernel(const float* __restrict__ x,
+                                                                const bf16_t* __restrict__ dy, long long lddy,
+                                                                int nimg, int H, int W, int Ho, int Wo, int stride,
+                                                                float in_scale, float in_shift,
+                                                                float* __restrict__ part) {
+  constexpr int ROWB = COUT * 2 + 16;
   constexpr int CC = COUT / 8;
-  constexpr int PPB = SP_THREADS / CC;
-  __shared__ float ldw[COUT * 9];
-  for (int i = threadIdx.x; i < COUT * 9; i += SP_THREADS) ldw[i] = 0.f;
-  __syncthreads();
-  const int c = (threadIdx.x % CC) * 8;
-  const int pl = threadIdx.x / CC;
+  constexpr int CPW = COUT / 4;                       // channels per wave
+  __shared__ __attribute__((aligned(16))) char tile[C1_TILE * ROWB];
+  __shared__ float xs[9][C1_TILE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long npix = (long long)nimg * Ho * Wo;
-  const long long step = (long long)gridDim.x * PPB;
-  float acc[8][9];
+  const int ntiles = (int)((npix + C1_TILE - 1) / C1_TILE);
+  float acc[CPW][9];
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
+  for (int c = 0; c < CPW; ++c)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) acc[q][t] = 0.f;
-  long long p = (long long)blockIdx.x * PPB + pl;
-  PixelWalk pw;
-  pw.init(p, step, Ho, Wo);
-#pragma unroll 2
-  for (; p < npix; p += step, pw.next()) {
-    float g[8];
-    unpack8s(*reinterpret_cast<const u32x4*>(dy + p * lddy + c), g);
-    const float* xi = x + (long long)pw.n * H * W;
+    for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const long long p0 = (long long)tl * C1_TILE;
+    __syncthreads();                                  // the previous tile has been consumed
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      int hi = pw.y * stride - 1 + r;
+    for (int i = 0; i < CC; ++i) {
+      int j = i * C1_TILE + threadIdx.x;
+      int px = j / CC, cc = j - px * CC;
+      u32x4 v = u32x4{0, 0, 0, 0};
+      if (p0 + px < npix) v = *reinterpret_cast<const u32x4*>(dy + (p0 + px) * lddy + cc * 8);
+      *reinterpret_cast<u32x4*>(tile + px * ROWB + cc * 16) = v;
+    }
+    float xv[9];
+    c1_taps(x, p0 + threadIdx.x, npix, H, W, Ho, Wo, stride, in_scale, in_shift, xv);
 #pragma unroll
-      for (int z = 0; z < 3; ++z) {
-        int wi = pw.x * stride - 1 + z;
-        bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
-        float v = ok ? xi[(long long)hi * W + wi] * in_scale + in_shift : 0.f;
+    for (int t = 0; t < 9; ++t) xs[t][threadIdx.x] = xv[t];
+    __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q][r * 3 + z] += g[q] * v;
+    for (int j = 0; j < C1_TILE / 64; ++j) {
+      const int px = lane + 64 * j;
+      float g[CPW], xt[9];
+#pragma unroll
+      for (int h = 0; h < CPW / 8; ++h) {
+        float f[8];
+        unpack8s(*reinterpret_cast<const u32x4*>(tile + px * ROWB + (wave * CPW + h * 8) * 2), f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g[h * 8 + q] = f[q];
       }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) xt[t] = xs[t][px];
+#pragma unroll
+      for (int c = 0; c < CPW; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] += g[c] * xt[t];
     }
   }
+  float* row = part + (long long)blockIdx.x * COUT * 9 + wave * CPW * 9;
 #pragma unroll
-  for (int q = 0; q < 8; ++q)
+  for (int c = 0; c < CPW; ++c)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) atomicAdd(&ldw[(c + q) * 9 + t], acc[q][t]);
-  __syncthreads();
-  float* row = part + (long long)blockIdx.x * COUT * 9;
-  for (int i = threadIdx.x; i < COUT * 9; i += SP_THREADS) row[i] = ldw[i];
+    for (int t = 0; t < 9; ++t) {
+      float v = wave_sum(acc[c][t]);
+      if (lane == 0) row[c * 9 + t] = v;
+    }
 }
 
 __global__ void rows_add_kernel(const float* __restrict__ part, int nrows, int Wd, float* __restrict__ out) {
@@ -211,14 +233,15 @@ extern "C" int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy
   RIED_CHECK_ARG(stride == 1 || stride == 2, "ried_conv_c1_wgrad: stride must be 1 or 2");
   RIED_CHECK_ARG(lddy % 8 == 0 && lddy >= Cout && ((uintptr_t)dy % 16) == 0, "ried_conv_c1_wgrad: dy view");
   RIED_CHECK_ARG(Cout == 32 || Cout == 64, "ried_conv_c1_wgrad: Cout must be 32 or 64");
+  RIED_CHECK_ARG((long long)H * W < (1ll << 31), "ried_conv_c1_wgrad: image too large");
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   long long npix = (long long)nimg * Ho * Wo;
-  int grid = ew_grid(npix, (SP_THREADS / (Cout / 8)) * 8, C1_WGRAD_MAX_ROWS);
+  int grid = ew_grid(npix, C1_TILE * 2, C1_WGRAD_MAX_ROWS);
   if (Cout == 32)
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel<32>, dim3(grid), dim3(SP_THREADS), 0, stream, x, (const bf16_t*)dy, lddy,
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel<32>, dim3(grid), dim3(C1_TILE), 0, stream, x, (const bf16_t*)dy, lddy,
                        nimg, H, W, Ho, Wo, stride, in_scale, in_shift, scratch);
   else
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel<64>, dim3(grid), dim3(SP_THREADS), 0, stream, x, (const bf16_t*)dy, lddy,
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel<64>, dim3(grid), dim3(C1_TILE), 0, stream, x, (const bf16_t*)dy, lddy,
                        nimg, H, W, Ho, Wo, stride, in_scale, in_shift, scratch);
   hipLaunchKernelGGL(rows_add_kernel, dim3(ceil_div(Cout * 9, 32)), dim3(256), 0, stream, scratch, grid, Cout * 9, dw);
   RIED_CHECK_LAUNCH("ried_conv_c1_wgrad");

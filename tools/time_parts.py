@@ -8,6 +8,7 @@ from reid_gan_amd.engine import State, Generator, Discriminator, Vgg
 from reid_gan_amd.synth import synth_batch
 
 B = 128
+ONLY = sys.argv[1] if len(sys.argv) > 1 else ""       # "G", "D" or "V": time (and profile) one network only
 g, d, vgg = bench.synth_states()
 x, y = synth_batch(B, 64, seed=1)
 x, y = x.cuda(), y.cuda()
@@ -27,22 +28,29 @@ def timeit(name, fn, reps=10):
 
 gs = State(g, "cuda"); G = Generator(gs, B, 64, 64)
 dout = torch.randn(B, 1, 64, 64, device="cuda")
-timeit("G forward", lambda: G.forward(x))
 def gfb():
     G.forward(x); gs.zero_grad(); G.backward(dout)
-timeit("G forward+backward", gfb)
+if ONLY in ("", "G"):
+    timeit("G forward", lambda: G.forward(x))
+    timeit("G forward+backward", gfb)
+if ONLY == "G":
+    sys.exit(0)
 ds = State(d, "cuda"); D = Discriminator(ds, 2 * B, 64, 64)
 din = torch.cat([y, x], 0).contiguous()
-timeit("D forward", lambda: D.forward(din))
 def dfb():
     out = D.forward(din); ds.zero_grad(); ops.fill(out.g, 1e-3); D.backward(0, 2 * B, wgrad=True)
-timeit("D forward+backward(wgrad)", dfb)
 def dgb():
     out = D.forward(din); ops.fill(out.g.images(B, 2 * B), 1e-3); D.backward(B, 2 * B, wgrad=False, dimg=dout)
-timeit("D forward+backward(data only, half)", dgb)
+if ONLY in ("", "D"):
+    timeit("D forward", lambda: D.forward(din))
+    timeit("D forward+backward(data only, half)", dgb)
+    timeit("D forward+backward(wgrad)", dfb)
+if ONLY == "D":
+    sys.exit(0)
 V = Vgg(vgg, B, 64, 64)
 loss = torch.zeros(1, device="cuda")
 def vfb():
     V.forward(din); V.loss_and_seed(loss, 0.3); V.backward(dout)
-timeit("VGG forward", lambda: V.forward(din))
-timeit("VGG forward+loss+backward", vfb)
+if ONLY in ("", "V"):
+    timeit("VGG forward", lambda: V.forward(din))
+    timeit("VGG forward+loss+backward", vfb)
