@@ -150,32 +150,33 @@ __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const long long*
   const long long stride = J[3], st = J[7], sp = J[8], sg = J[9];
   const int E = taps * Cg;
   const bool contiguous = st == 1 && sg == taps && E <= WRED_MAX_ROW;
-  constexpr int U = 4;
-  for (int e0 = threadIdx.x; e0 < E; e0 += 256 * U) {
-    float acc[U];
-    long long base[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int e = e0 + u * 256;
-      int tap = e / Cg, g = e - tap * Cg;
-      base[u] = ((long long)tap * Cp + p) * Cg + g;
-      acc[u] = 0.f;
+  // 256 threads = Ew elements x KT lanes over the splits (short rows would otherwise leave most threads idle and
+  // each busy thread with a long chain of dependent-latency loads)
+  __shared__ float ksum[256];
+  const int Ew = E < 256 ? E : 256, KT = 256 / Ew;
+  const int el = threadIdx.x % Ew, kl = threadIdx.x / Ew;
+  for (int e0 = 0; e0 < E; e0 += Ew) {
+    const int e = e0 + el;
+    const bool live = kl < KT && e < E;
+    const int tap = live ? e / Cg : 0, g = live ? e - tap * Cg : 0;
+    float acc = 0.f;
+    if (live) {
+      const float* s = slab + ((long long)tap * Cp + p) * Cg + g;
+#pragma unroll 4
+      for (int k = kl; k < splitk; k += KT) acc += s[k * stride];
     }
-    for (int k = 0; k < splitk; ++k) {          // U independent loads in flight per split
-      const float* s = slab + k * stride;
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (e0 + u * 256 < E) acc[u] += s[base[u]];
+    if (KT > 1) {
+      ksum[threadIdx.x] = acc;
+      __syncthreads();
+      if (live && kl == 0)
+        for (int q = 1; q < KT; ++q) acc += ksum[q * Ew + el];
+      __syncthreads();
     }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      int e = e0 + u * 256;
-      if (e >= E) break;
-      int tap = e / Cg, g = e - tap * Cg;
-      if (contiguous) rowbuf[g * taps + tap] = acc[u];
+    if (live && kl == 0) {
+      if (contiguous) rowbuf[g * taps + tap] = acc;
       else {
         float* o = out + tap * st + p * sp + g * sg;
-        *o = J[10] ? *o + acc[u] : acc[u];
+        *o = J[10] ? *o + acc : acc;
       }
     }
   }

@@ -234,8 +234,9 @@ _side_streams: List["torch.cuda.Stream"] = []
 
 
 def side_stream(lane: int):
-    """Process-wide side streams for lanes 1..N_LANES-1 (lane 0 is the caller's current stream)."""
-    while len(_side_streams) < N_LANES - 1:
+    """Process-wide side streams: 1..N_LANES-1 for the branches of a Par (lane 0 is the caller's current stream);
+    higher numbers for whole networks run beside each other (train_step)."""
+    while len(_side_streams) < lane:
         _side_streams.append(torch.cuda.Stream())
     return _side_streams[lane - 1]
 
@@ -290,7 +291,8 @@ class Slot:
 
 def _splitk(blocks: int, kpix: int, target: int = 0) -> int:
     target = target or int(os.environ.get("RIED_SPLITK_TARGET", "384"))
-    s = max(1, min((target + blocks - 1) // blocks, (kpix + 127) // 128))
+    minpix = int(os.environ.get("RIED_SPLITK_MINPIX", "256"))
+    s = max(1, min((target + blocks - 1) // blocks, (kpix + minpix - 1) // minpix))
     return min(s, 512)
 
 
@@ -1089,15 +1091,20 @@ class Vgg:
         ctx.finalize()
         torch.cuda.synchronize()
 
-    def forward(self, imgs: torch.Tensor):
-        """imgs: fp32 (2B,1,H,W): prediction images first, then targets."""
-        ops.conv_c1_fwd(imgs, self.w0, self.a0.v, 1, bias=self.b0, in_scale=1.0 / 4096.0, in_shift=0.25, act=1)
+    def forward(self, imgs: torch.Tensor, n0: int = 0, n1: Optional[int] = None):
+        """imgs: fp32 (2B,1,H,W): prediction images first, then targets.  Only images [n0, n1) are processed, so
+        the target half can run early, beside other work, and the prediction half once it exists."""
+        n1 = 2 * self.B if n1 is None else n1
+        a0 = self.a0.images(n0, n1)
+        ops.conv_c1_fwd(imgs[n0:n1], self.w0, a0.v, 1, bias=self.b0, in_scale=1.0 / 4096.0, in_shift=0.25, act=1)
         for l in self.layers:
             if l[0] == "pool":
-                l[1].forward()
+                p = l[1]
+                ops.pool_fwd(p.xin.images(n0, n1).v, p.out.images(n0, n1).v, p.mode)
             else:
                 _, core, bias, out, tap32 = l[:5]
-                core.conv(out.v, bias=bias, act=1, y2=tap32)
+                ops.conv2d(core.xin.images(n0, n1).v, core.wp, out.images(n0, n1).v, 3, 3, 1, 1, 1, 1, bias=bias, act=1,
+                           y2=None if tap32 is None else tap32[n0:n1])
 
     def loss_and_seed(self, loss: torch.Tensor, weight: float):
         """loss[0] += mean over taps of MSE(tap(pred), tap(target)); seeds each tap's gradient (prediction

@@ -25,7 +25,7 @@ import torch
 
 from . import ops
 from .dp import allreduce_mean
-from .engine import Discriminator, Generator, State, Vgg
+from .engine import Discriminator, Generator, State, Vgg, side_stream, N_LANES
 
 F32 = torch.float32
 
@@ -61,6 +61,9 @@ class TrainStep:
         self.ssim_sums = torch.zeros(B, 4, dtype=F32, device=device)
         self.gmap = torch.empty(3, B, H, W, dtype=F32, device=device)
         self.use_graph = use_graph
+        import os
+        self.overlap_vgg = not os.environ.get("RIED_NO_OVERLAP_VGG")
+        self.overlap_gbwd = not os.environ.get("RIED_NO_OVERLAP_GBWD")
         self.graphs = None          # [(graph, tensor to all-reduce after it or None)]
         self.steps_done = 0
 
@@ -73,6 +76,24 @@ class TrainStep:
     # yields are skipped and the whole step is one HIP graph; with several ranks each stretch between two
     # collectives is its own graph and the RCCL all-reduces are issued between the replays on the same stream,
     # so nothing synchronises with the host either way.
+    # Two whole-network overlaps on side streams (graph capture records them as parallel paths):
+    #  * the VGG features of the TARGET images depend on nothing the step computes, so they run beside the
+    #    generator forward, whose small layers leave most of the chip idle;
+    #  * the generator backward (small, latency-bound kernels) runs beside the last discriminator backward and
+    #    Adam step (large kernels); both only need what the generator-loss backward has produced by then.
+    @staticmethod
+    def _fork(lane: int, enabled: bool = True):
+        if not enabled:
+            return torch.cuda.current_stream()
+        s = side_stream(lane)
+        s.wait_stream(torch.cuda.current_stream())
+        return s
+
+    @staticmethod
+    def _join(s):
+        if s != torch.cuda.current_stream():
+            torch.cuda.current_stream().wait_stream(s)
+
     def _d_iteration(self, last: bool):
         B, sc, D = self.B, self.sc, self.D
         out = D.forward(self.d_in)
@@ -83,25 +104,37 @@ class TrainStep:
         yield sc[SC_MEAN_POS:SC_MEAN_NEG + 1]            # the hinge acts on the GLOBAL batch means
         ops.dloss_scalars(sc, n)
         sc[SC_DLOSS2 if last else SC_DLOSS1].copy_(sc[SC_DLOSS])
-        D.ctx.zero_backward()
-        self.ds.zero_grad()
-        ops.fill(out.g.images(0, B), 1.0, s=sc[SC_CPOS:])
-        ops.fill(out.g.images(B, 2 * B), 1.0, s=sc[SC_CNEG:])
-        D.backward(0, 2 * B, wgrad=True)
-        yield self.ds.flat_grad
+        if last:       # the generator's gradient goes through D as it is now; D's own backward reuses the buffers after
+            self._g_loss_backward(n)
+        # D's own backward (large kernels) on a side stream, the generator backward (small, latency-bound
+        # kernels; its Inception branches fork from the stream it runs on) on the main one
+        side = self._fork(N_LANES + 1, last and self.overlap_gbwd)
+        with torch.cuda.stream(side):
+            D.ctx.zero_backward()
+            self.ds.zero_grad()
+            ops.fill(out.g.images(0, B), 1.0, s=sc[SC_CPOS:])
+            ops.fill(out.g.images(B, 2 * B), 1.0, s=sc[SC_CNEG:])
+            D.backward(0, 2 * B, wgrad=True)
         if last:
-            yield from self._g_loss_backward(n)
+            self.gs.zero_grad()
+            self.G.backward(self.dpred)
+            self._join(side)
+        yield self.ds.flat_grad
         self.ds.adam(4.0 * self.lr)
+        if last:
+            yield self.gs.flat_grad
 
     def _g_loss_backward(self, n: int):
         B, H, W, sc = self.B, self.H, self.W, self.sc
         pred, y = self.G.out, self.y
         self.dpred.zero_()
         sc[SC_VGG:SC_SSIM + 1].zero_()
-        # perceptual term (loss.py:179-189)
+        # perceptual term (loss.py:179-189); the target half of the features was started in _body()
         self.v_in[:B].copy_(pred)
-        self.v_in[B:].copy_(y)
-        self.V.forward(self.v_in)
+        self.V.forward(self.v_in, 0, B)
+        if self._vgg_side is not None:
+            self._join(self._vgg_side)
+            self._vgg_side = None
         self.V.ctx.zero_backward()
         self.V.loss_and_seed(sc[SC_VGG:], self.wv)
         self.V.backward(self.dpred)
@@ -116,13 +149,17 @@ class TrainStep:
         ops.fill(out.g.images(B, 2 * B), -self.wg / n)
         self.D.backward(B, 2 * B, wgrad=False, dimg=self.dpred)
         ops.gloss_scalars(sc, self.wv, self.ws, self.wg)
-        self.gs.zero_grad()
-        self.G.backward(self.dpred)
-        yield self.gs.flat_grad
 
     def _body(self):
         B = self.B
+        self._vgg_side = self._fork(N_LANES, self.overlap_vgg)      # target features beside the generator forward
+        with torch.cuda.stream(self._vgg_side):
+            self.v_in[B:].copy_(self.y)
+            self.V.forward(self.v_in, B, 2 * B)
         pred = self.G.forward(self.x)
+        if self.world > 1:           # a side stream may not stay open across a collective (graph segment boundary)
+            self._join(self._vgg_side)
+            self._vgg_side = None
         self.d_in[:B].copy_(self.y)
         self.d_in[B:].copy_(pred)
         yield from self._d_iteration(last=False)
