@@ -70,6 +70,16 @@ int ried_conv2d_force_tile(int bm, int bn, int nst);
 int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg, int H, int W, const void* p, long long ldp,
                       int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw, float* slab, int splitk,
                       ried_stream_t stream);
+/* Job-table form: the weight gradients of many layers in one launch per tile shape (the reference launches one
+ * cuDNN weight-gradient per layer from autograd).  ried_conv2d_wgrad_make_job fills a HOST record of
+ * ried_conv2d_wgrad_job_bytes() bytes for one layer (arguments as ried_conv2d_wgrad) and reports tile[2] (its
+ * tile shape) and its block count; records of one tile shape, copied to the device back to back, are launched by
+ * ried_conv2d_wgrad_jobs with map[b] = (job, block of that job) for b < nblocks. */
+int ried_conv2d_wgrad_job_bytes(void);
+int ried_conv2d_wgrad_make_job(void* job_host, const void* g, long long ldg, int Cg, int nimg, int H, int W,
+                               const void* p, long long ldp, int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw,
+                               int ph, int pw, float* slab, int splitk, int* tile, int* nblocks);
+int ried_conv2d_wgrad_jobs(const void* jobs, const int* map, int nblocks, int bm, int bn, ried_stream_t stream);
 int ried_conv2d_wgrad_tiles(int Cg, int Cp); /* blocks per (tap, split) of ried_conv2d_wgrad: for choosing splitk */
 /* out[tap*st + p*sp + g*sg] (+)= scale * sum over splits: scatters into the (Cout,Cin,kh,kw) or (Cin,Cout,kh,kw)
  * fp32 master gradient. */

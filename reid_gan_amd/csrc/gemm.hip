@@ -67,6 +67,7 @@ struct GemmParams {
   int splitk;
   int tiles_m;
   unsigned A_bytes, B_bytes;   // extent of the operands in bytes (buffer descriptors of the LDS-DMA kernel)
+  int grid[3];                 // the problem's own grid (job-table launches)
 };
 
 constexpr int BK = 64;                            // k per stage: two MFMA k-slices of 32
@@ -273,15 +274,16 @@ __device__ __forceinline__ bf16x8_t read_frag(const bf16_t* lds, int rowbase, in
 // ---------------------------------------------------------------------------
 template <int BM, int BN, bool WGRAD>
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0,
-                                              int tn, int pa, int pb, long long batch, int ntiles_n, void* smem) {
+                                              int tn, int pa, int pb, long long batch, int ntiles_n, int by, int bz,
+                                              unsigned nblocks, void* smem) {
   constexpr int TM = BM / 32, TN = BN / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const GemmEpilogue& E = P.E;
   const float gam = E.gamma ? E.gamma[0] : 0.f;
   char* outb = (char*)E.out;
-  long long obase = batch * E.batch_stride + (long long)blockIdx.y * E.tap_stride;
-  if constexpr (WGRAD) obase += (long long)blockIdx.z * E.batch_stride;
+  long long obase = batch * E.batch_stride + (long long)by * E.tap_stride;
+  if constexpr (WGRAD) obase += (long long)bz * E.batch_stride;
   float ssum[TM][4], ssq[TM][4];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -377,7 +379,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
     }
     __syncthreads();
     if (wn == 0 && (lane & 15) == 0) {
-      float* row = E.stats + ((long long)blockIdx.y * ntiles_n + tn) * 2 * P.M;
+      float* row = E.stats + ((long long)by * ntiles_n + tn) * 2 * P.M;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -397,14 +399,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
     }
     if (E.fin.counter) {       // fused BatchNorm finalize: saves a dependent launch per layer
       float* scratch = reinterpret_cast<float*>(smem) + 1024;
-      if (ried_last_block(E.fin.counter, gridDim.x * gridDim.y * gridDim.z, reinterpret_cast<int*>(smem) + 768))
+      if (ried_last_block(E.fin.counter, nblocks, reinterpret_cast<int*>(smem) + 768))
         bn_finalize_rows(E.stats, P.M, E.fin, scratch);
     }
   }
 }
 
+// (bx, by, bz): the block's position in the problem's own grid: tile, tap or phase, k split or batch
 template <int BM, int BN, int AKIND, int BKIND>
-__global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
+__device__ __forceinline__ void igemm_body(const GemmParams& P, int bx, int by, int bz, int ntiles_n,
+                                           unsigned nblocks) {
   using GA = TileGeom<BM>;
   using GB = TileGeom<BN>;
   constexpr int TM = BM / 32, TN = BN / 32;       // 16x16 tiles per wave (2x2 waves)
@@ -413,7 +417,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int tm = blockIdx.x % P.tiles_m, tn = blockIdx.x / P.tiles_m;
+  const int tm = bx % P.tiles_m, tn = bx / P.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
 
   // block-uniform schedule
@@ -423,21 +427,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
   long long batch = 0;
   int kbeg = 0, kend = P.K;
   if constexpr (CONV) {
-    if (P.B.transposed) {                 // blockIdx.y = output phase
-      pa = blockIdx.y / P.B.sw; pb = blockIdx.y % P.B.sw;
+    if (P.B.transposed) {                 // by = output phase
+      pa = by / P.B.sw; pb = by % P.B.sw;
       r0 = (pa + P.B.ph) % P.B.sh; s0 = (pb + P.B.pw) % P.B.sw;
       int nr = (P.B.kh - r0 + P.B.sh - 1) / P.B.sh, ns = (P.B.kw - s0 + P.B.sw - 1) / P.B.sw;
       tj_n = ns; taps = nr * ns;
     } else {
       tj_n = P.B.kw;
     }
-  } else if constexpr (WGRAD) {           // blockIdx.y = tap, blockIdx.z = k split
-    r0 = blockIdx.y / P.A.kw; s0 = blockIdx.y % P.A.kw;
+  } else if constexpr (WGRAD) {           // by = tap, bz = k split
+    r0 = by / P.A.kw; s0 = by % P.A.kw;
     int per = ((P.K + P.splitk - 1) / P.splitk + BK - 1) / BK * BK;
-    kbeg = blockIdx.z * per;
+    kbeg = bz * per;
     kend = min(P.K, kbeg + per);
   } else {
-    batch = blockIdx.z;
+    batch = bz;
   }
 
   Loader<AKIND, BM> la;
@@ -519,7 +523,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
     __syncthreads();
   }
 
-  gemm_epilogue<BM, BN, WGRAD>(P, acc, m0, n0, tn, pa, pb, batch, gridDim.x / P.tiles_m, smem);
+  gemm_epilogue<BM, BN, WGRAD>(P, acc, m0, n0, tn, pa, pb, batch, ntiles_n, by, bz, nblocks, smem);
+}
+
+template <int BM, int BN, int AKIND, int BKIND>
+__global__ __launch_bounds__(256) void igemm_kernel(const GemmParams P) {
+  igemm_body<BM, BN, AKIND, BKIND>(P, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x / P.tiles_m,
+                                   gridDim.x * gridDim.y * gridDim.z);
+}
+
+// Job-table form: many independent problems of one tile shape in one launch.  map[b] = (job, block of that job);
+// a job's blocks are numbered x fastest, then y, then z, with its own grid in GemmParams::grid.
+template <int BM, int BN, int AKIND, int BKIND>
+__global__ __launch_bounds__(256) void igemm_jobs_kernel(const GemmParams* __restrict__ jobs,
+                                                         const int* __restrict__ map) {
+  const GemmParams& P = jobs[map[2 * blockIdx.x]];
+  const int lb = map[2 * blockIdx.x + 1];
+  const int nx = P.grid[0], ny = P.grid[1];
+  const int bx = lb % nx, r = lb / nx;
+  igemm_body<BM, BN, AKIND, BKIND>(P, bx, r % ny, r / ny, nx / P.tiles_m, nx * ny * P.grid[2]);
 }
 
 // ---------------------------------------------------------------------------
@@ -674,7 +696,8 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may outlive the block or race the epilogue
   __builtin_amdgcn_s_barrier();
-  gemm_epilogue<BM, BN, false>(P, acc, m0, n0, tn, pa, pb, 0, gridDim.x / P.tiles_m, smem);
+  gemm_epilogue<BM, BN, false>(P, acc, m0, n0, tn, pa, pb, 0, gridDim.x / P.tiles_m, blockIdx.y, 0,
+                               gridDim.x * gridDim.y, smem);
 }
 
 // Tile of the convolution kernel for a problem: Cout x pixels per phase.  Small problems take 64-pixel tiles
@@ -832,13 +855,9 @@ extern "C" int ried_conv2d_bn(const void* x, long long ldx, const void* w, void*
                      stats, 0, 0, nullptr, 0, nullptr, 0, 0.f, 0, &f, stream);
 }
 
-// Weight gradient partial sums.  g: the tensor that is gathered through the kernel window
-// (the conv input; for a ConvTranspose2d layer, the output gradient), NHWC bf16 [nimg][H][W][ldg], Cg channels.
-// p: the tensor indexed by output pixel (conv: output gradient; ConvTranspose2d: the layer input),
-// NHWC bf16 [nimg][Ho][Wo][ldp], Cp channels.   slab: fp32 [splitk][kh*kw][Cp][Cg].
-extern "C" int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg, int H, int W, const void* p,
-                                 long long ldp, int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw,
-                                 float* slab, int splitk, hipStream_t stream) {
+static int wgrad_params(GemmParams& P, const void* g, long long ldg, int Cg, int nimg, int H, int W, const void* p,
+                        long long ldp, int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw,
+                        float* slab, int splitk, int& bm, int& bn) {
   RIED_CHECK_ARG(g && p && slab, "ried_conv2d_wgrad: null pointer");
   RIED_CHECK_ARG(Cg % 8 == 0 && Cp % 8 == 0 && ldg % 8 == 0 && ldp % 8 == 0, "ried_conv2d_wgrad: channels %% 8");
   RIED_CHECK_ARG(((uintptr_t)g % 16) == 0 && ((uintptr_t)p % 16) == 0 && ((uintptr_t)slab % 16) == 0,
@@ -848,7 +867,6 @@ extern "C" int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg,
   RIED_CHECK_ARG(splitk >= 1 && splitk <= 65535, "ried_conv2d_wgrad: bad splitk");
   long long npix = (long long)nimg * Ho * Wo;
   RIED_CHECK_ARG(npix < (1ll << 30) && (long long)nimg * H * W < (1ll << 30), "ried_conv2d_wgrad: too many pixels");
-  GemmParams P;
   memset(&P, 0, sizeof(P));
   default_epilogue(P.E);
   P.A.p = (const bf16_t*)g; P.A.ld = ldg; P.A.rows = Cg; P.A.C = Cg;
@@ -859,15 +877,67 @@ extern "C" int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg,
   P.E.out = slab; P.E.ldc = Cg; P.E.out_f32 = 1;
   P.E.tap_stride = (long long)Cp * Cg;
   P.E.batch_stride = (long long)kh * kw * Cp * Cg;      // per split
-  const int bm = Cg <= 64 ? 64 : 128, bn = Cp <= 64 ? 64 : 128;      // ried_conv2d_wgrad_tiles mirrors this
+  bm = Cg <= 64 ? 64 : 128; bn = Cp <= 64 ? 64 : 128;    // ried_conv2d_wgrad_tiles mirrors this
   P.tiles_m = ceil_div(Cg, bm);
-  dim3 grid(P.tiles_m * ceil_div(Cp, bn), kh * kw, splitk);
+  P.grid[0] = P.tiles_m * ceil_div(Cp, bn); P.grid[1] = kh * kw; P.grid[2] = splitk;
+  return RIED_OK;
+}
+
+// Weight gradient partial sums.  g: the tensor that is gathered through the kernel window
+// (the conv input; for a ConvTranspose2d layer, the output gradient), NHWC bf16 [nimg][H][W][ldg], Cg channels.
+// p: the tensor indexed by output pixel (conv: output gradient; ConvTranspose2d: the layer input),
+// NHWC bf16 [nimg][Ho][Wo][ldp], Cp channels.   slab: fp32 [splitk][kh*kw][Cp][Cg].
+extern "C" int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg, int H, int W, const void* p,
+                                 long long ldp, int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw,
+                                 float* slab, int splitk, hipStream_t stream) {
+  GemmParams P;
+  int bm, bn;
+  int rc = wgrad_params(P, g, ldg, Cg, nimg, H, W, p, ldp, Cp, Ho, Wo, kh, kw, sh, sw, ph, pw, slab, splitk, bm, bn);
+  if (rc) return rc;
+  dim3 grid(P.grid[0], P.grid[1], P.grid[2]);
   if (bm == 64 && bn == 64) launch<64, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
   else if (bm == 64) launch<64, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
   else if (bn == 64) launch<128, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
   else launch<128, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
   RIED_CHECK_LAUNCH("ried_conv2d_wgrad");
   return RIED_OK;
+}
+
+// Job-table form of ried_conv2d_wgrad: the weight gradients of many layers in one launch per tile shape.
+//   ried_conv2d_wgrad_job_bytes(): size of one job record.
+//   ried_conv2d_wgrad_make_job(): fills a HOST record for one layer (same arguments as ried_conv2d_wgrad) and
+//     reports its tile shape (tile[0] x tile[1]) and block count; records of one tile shape are copied to the
+//     device back to back and launched with ried_conv2d_wgrad_jobs, map[b] = (job, block of that job).
+extern "C" int ried_conv2d_wgrad_job_bytes(void) { return (int)sizeof(GemmParams); }
+
+extern "C" int ried_conv2d_wgrad_make_job(void* job_host, const void* g, long long ldg, int Cg, int nimg, int H, int W,
+                                          const void* p, long long ldp, int Cp, int Ho, int Wo, int kh, int kw, int sh,
+                                          int sw, int ph, int pw, float* slab, int splitk, int* tile, int* nblocks) {
+  RIED_CHECK_ARG(job_host && tile && nblocks, "ried_conv2d_wgrad_make_job: null pointer");
+  GemmParams P;
+  int rc = wgrad_params(P, g, ldg, Cg, nimg, H, W, p, ldp, Cp, Ho, Wo, kh, kw, sh, sw, ph, pw, slab, splitk, tile[0],
+                        tile[1]);
+  if (rc) return rc;
+  memcpy(job_host, &P, sizeof(P));
+  *nblocks = P.grid[0] * P.grid[1] * P.grid[2];
+  return RIED_OK;
+}
+
+extern "C" int ried_conv2d_wgrad_jobs(const void* jobs, const int* map, int nblocks, int bm, int bn,
+                                      hipStream_t stream) {
+  RIED_CHECK_ARG(jobs && map && nblocks > 0, "ried_conv2d_wgrad_jobs: bad arguments");
+  const GemmParams* J = (const GemmParams*)jobs;
+#define RIED_WJ(BM_, BN_)                                                                                  \
+  if (bm == BM_ && bn == BN_) {                                                                            \
+    hipLaunchKernelGGL((igemm_jobs_kernel<BM_, BN_, OP_GATHER_TR, OP_PLAIN_TR>), dim3(nblocks), dim3(256), 0, \
+                       stream, J, map);                                                                    \
+    RIED_CHECK_LAUNCH("ried_conv2d_wgrad_jobs");                                                           \
+    return RIED_OK;                                                                                        \
+  }
+  RIED_WJ(64, 64) RIED_WJ(64, 128) RIED_WJ(128, 64) RIED_WJ(128, 128)
+#undef RIED_WJ
+  ried_set_error("ried_conv2d_wgrad_jobs: no kernel for tile %dx%d", bm, bn);
+  return RIED_ERR_ARG;
 }
 
 // output tiles (blocks per tap and split) of ried_conv2d_wgrad for Cg x Cp: for choosing splitk

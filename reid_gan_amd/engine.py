@@ -129,6 +129,8 @@ class Ctx:
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
         self.wreds = ops.JobTable(11)      # every weight-gradient slab reduction: one launch (end_backward)
         self.sn = ops.SnJobs()             # every spectral-norm layer: power iteration / sigma gradient per launch
+        self.wgrads = ops.WgradJobs()      # deferred weight gradients: one launch per tile shape (end_backward)
+        self._late: List = []              # callbacks run by finalize() once every buffer has its address
         self._wred_slab: List[Tuple[int, int]] = []      # (job, slab offset) patched once the arena exists
 
     # activations
@@ -185,9 +187,12 @@ class Ctx:
         self.slab = torch.empty(max(self.slab_elems, 4), dtype=F32, device=dev)
         for j, off in self._wred_slab:
             self.wreds.rows[j][0] = self.slab.data_ptr() + 4 * off
+        for fn in self._late:
+            fn()
         self.packs.finalize(dev)
         self.wreds.finalize(dev)
         self.sn.finalize(dev)
+        self.wgrads.finalize(dev)
         # one scratch set per lane: branches of a Par run concurrently on their own streams
         self.tmps = [torch.empty(max(self.tmp_elems, 8), dtype=torch.bfloat16, device=dev) for _ in range(N_LANES)]
         self.f32s = [torch.empty(max(self.f32_elems, 4), dtype=F32, device=dev) for _ in range(N_LANES)]
@@ -224,7 +229,9 @@ class Ctx:
             ops.sn_backward_jobs(self.sn)
 
     def end_backward(self):
-        """Reduce the weight-gradient slabs of every layer into the master gradients (one launch)."""
+        """The deferred weight gradients (one launch per tile shape), then the reduction of every layer's slabs
+        into the master gradients (one launch)."""
+        self.wgrads.launch()
         ops.wgrad_reduce_jobs(self.wreds)
 
 
@@ -358,8 +365,22 @@ class ConvCore:
         ops.conv2d(dy, self.wpt, dx, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
                    transposed=not self.deconv, accumulate=accumulate, **kw)
 
+    def defer_wgrad(self, dy_of):
+        """Compute this layer's weight gradient in Ctx.end_backward(), together with every other deferred layer,
+        instead of in its own launch.  dy_of(): the view that will hold d loss / d conv output at that point (it
+        must not be a scratch buffer that later layers overwrite); called once all buffers have addresses."""
+        def make():
+            dy, x = dy_of(), self.xin.v
+            g, p = (dy, x) if self.deconv else (x, dy)
+            self.ctx.wgrads.add(g, p, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
+                                self.ctx.slab_at(self.slab_off), self.splitk)
+        self.ctx._late.append(make)
+        self.deferred = True
+
     def wgrad(self, dy: View, x: Optional[View] = None):
         """Split-K partial weight gradients into this layer's slab; Ctx.end_backward() reduces all layers."""
+        if getattr(self, "deferred", False):
+            return
         ctx = self.ctx
         x = self.xin.v if x is None else x
         slab = ctx.slab_at(self.slab_off)
@@ -389,9 +410,13 @@ class ConvBN:
         self.counters = torch.zeros(2, dtype=torch.int32, device=ctx.device)    # last-block tickets: fwd, bwd
         self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, c.cout, c.sh, c.sw, deconv)
         ctx.stats(self, "stats", self.stat_rows * 2 * cout)
+        self.draw: Optional[View] = None
         if ctx.grads:
             ctx.need_f32(ops.bn_backward_scratch_floats(cout))
-            ctx.need_tmp(c.N * c.Ho * c.Wo * cout)
+            # the gradient w.r.t. the conv output keeps its own buffer, so that the weight gradient can wait for
+            # the grouped launch at the end of the backward pass
+            self.draw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
+            c.defer_wgrad(lambda: self.draw)
 
     def forward(self):
         ctx, c, st = self.ctx, self.core, self.ctx.st
@@ -419,7 +444,7 @@ class ConvBN:
     def backward_local(self):
         """Everything that touches only this layer's own buffers (safe to run beside sibling branches)."""
         ctx, c, st = self.ctx, self.core, self.ctx.st
-        draw = ctx.tmp_view(c.N, c.Ho, c.Wo, c.cout, self.lane)
+        draw = self.draw
         ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
                         ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True,
                         counter=self.counters[1:] if self.raw.npix * c.cout <= FUSE_MAX_ROWS * 8192 else None)
@@ -429,7 +454,7 @@ class ConvBN:
         """xin.g += data gradient; the lane's temp still holds the pre-BN gradient from backward_local()."""
         c = self.core
         if c.need_dx:
-            c.dgrad(self.ctx.tmp_view(c.N, c.Ho, c.Wo, c.cout, self.lane), c.xin.g)
+            c.dgrad(self.draw, c.xin.g)
 
 
 class ConvBNC1:
@@ -478,6 +503,8 @@ class ConvPlain:
     def __init__(self, ctx: Ctx, wname: str, cin, cout, xin: Slot, out: Slot):
         self.ctx, self.out = ctx, out
         self.core = ConvCore(ctx, wname, cin, cout, 1, 1, 0, False, xin, True)
+        if ctx.grads:
+            self.core.defer_wgrad(lambda: self.out.g)     # the gradient arena keeps out.g until the next backward
 
     def forward(self):
         self.core.conv(self.out.v)

@@ -89,6 +89,35 @@ def conv2d_wgrad(g: View, p: View, kh, kw, sh, sw, ph, pw, slab, splitk: int):
                           slab if isinstance(slab, int) else _p(slab), splitk, _stream())
 
 
+class WgradJobs:
+    """Weight gradients of many layers, launched together (one launch per tile shape)."""
+
+    def __init__(self):
+        self.groups = {}           # (bm, bn) -> [records], [block counts]
+        self.dev = []
+
+    def add(self, g: View, p: View, kh, kw, sh, sw, ph, pw, slab_ptr: int, splitk: int):
+        import numpy as np
+        rec = np.zeros(lib.ried_conv2d_wgrad_job_bytes(), dtype=np.uint8)
+        tile, nb = np.zeros(2, dtype=np.int32), np.zeros(1, dtype=np.int32)
+        lib.ried_conv2d_wgrad_make_job(rec.ctypes.data, g.ptr, g.ld, g.C, g.N, g.H, g.W, p.ptr, p.ld, p.C, p.H, p.W,
+                                       kh, kw, sh, sw, ph, pw, slab_ptr, splitk, tile.ctypes.data, nb.ctypes.data)
+        recs, counts = self.groups.setdefault((int(tile[0]), int(tile[1])), ([], []))
+        recs.append(rec); counts.append(int(nb[0]))
+
+    def finalize(self, device):
+        import numpy as np
+        self.dev = []
+        for (bm, bn), (recs, counts) in sorted(self.groups.items()):
+            jobs = torch.from_numpy(np.concatenate(recs)).to(device)
+            m = np.asarray([(j, b) for j, c in enumerate(counts) for b in range(c)], dtype=np.int32).reshape(-1)
+            self.dev.append((bm, bn, jobs, torch.from_numpy(m).to(device), sum(counts)))
+
+    def launch(self):
+        for bm, bn, jobs, m, n in self.dev:
+            lib.ried_conv2d_wgrad_jobs(_p(jobs), _p(m), n, bm, bn, _stream())
+
+
 def conv2d_wgrad_tiles(Cg, Cp) -> int:
     return lib.ried_conv2d_wgrad_tiles(Cg, Cp)
 
