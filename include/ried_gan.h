@@ -59,7 +59,8 @@ int ried_conv2d_bn(const void* x, long long ldx, const void* w, void* y, long lo
 /* out[c] += sum over rows of stats[r][0][c] (stats: [nrows][2][C], as written by ried_conv2d) */
 int ried_stat_rows_sum(const float* stats, int nrows, int C, float* out, ried_stream_t stream);
 
-int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int Cout, int sh, int sw, int transposed);
+int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int sh, int sw,
+                          int transposed);
 /* tuning hook, no counterpart in the reference: force the (Cout tile, pixel tile, LDS stages) of later ried_conv2d
  * calls; bm = 0 restores the built-in choice */
 int ried_conv2d_force_tile(int bm, int bn, int nst);

@@ -251,8 +251,10 @@ def side_stream(lane: int):
 class _Fused:
     """Stats rows a data-gradient epilogue fills with the column sums of the masked gradient it writes."""
 
-    def __init__(self, ctx: "Ctx", nimg, H, W, C, sh, sw):
-        self.rows = ops.conv2d_stat_rows(nimg, H, W, C, sh, sw, True)
+    def __init__(self, ctx: "Ctx", nimg, H, W, Cin, C, k, sh, sw):
+        """The data gradient is a transposed conv with Cin input channels (the layer's outputs) producing an
+        (nimg, H, W, C) tensor."""
+        self.rows = ops.conv2d_stat_rows(nimg, H, W, Cin, C, k, k, sh, sw, True)
         self.C = C
         ctx.stats(self, "stats", self.rows * 2 * C)
 
@@ -408,7 +410,7 @@ class ConvBN:
         self.raw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
         self.counters = torch.zeros(2, dtype=torch.int32, device=ctx.device)    # last-block tickets: fwd, bwd
-        self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, c.cout, c.sh, c.sw, deconv)
+        self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, cin, c.cout, c.kh, c.kw, c.sh, c.sw, deconv)
         ctx.stats(self, "stats", self.stat_rows * 2 * cout)
         self.draw: Optional[View] = None
         if ctx.grads:
@@ -856,7 +858,7 @@ class SNConv:
             out.act.fuse_slope = 0.2          # whoever writes out.g may apply this layer's LeakyReLU backward
             if not first and xin.act.fuse_slope is not None:
                 _, H, W, _ = xin.shape
-                xin.act.fused = _Fused(ctx, N, H, W, cin, stride, stride)
+                xin.act.fused = _Fused(ctx, N, H, W, cout, cin, 3, stride, stride)
         st = ctx.st
         ctx.sn.add(st.p[prefix + ".weight_orig"], st.b[prefix + ".weight_u"], st.b[prefix + ".weight_v"], self.sigma,
                    cout, self.K, self.dwsn, st.g[prefix + ".weight_orig"] if ctx.grads else None)
@@ -942,7 +944,7 @@ class Attn:
             ctx.add_wgrad_reduce(self.slab_off, self.dw, self.splitk, 1, self.cq, C, 1, C, 1)
             ctx.need_f32(ops.colsum_scratch_floats(self.cq))
             if xin.act.fuse_slope is not None:
-                xin.act.fused = _Fused(ctx, N, H, W, C, 1, 1)
+                xin.act.fused = _Fused(ctx, N, H, W, self.cq, C, 1, 1, 1)
 
     def _names(self):
         p = self.prefix

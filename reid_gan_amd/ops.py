@@ -216,8 +216,9 @@ def sn_backward_jobs(j: SnJobs, accumulate=False):
 
 
 # --------------------------------------------------------------------------- batch norm
-def conv2d_stat_rows(nimg, Ho, Wo, Cout, sh=1, sw=1, transposed=False) -> int:
-    return lib.ried_conv2d_stat_rows(nimg, Ho, Wo, Cout, sh, sw, int(transposed))
+def conv2d_stat_rows(nimg, Ho, Wo, Cin, Cout, kh, kw, sh=1, sw=1, transposed=False) -> int:
+    """Rows of the stats buffer a conv2d call with these dimensions (Ho, Wo: its output) writes."""
+    return lib.ried_conv2d_stat_rows(nimg, Ho, Wo, Cin, Cout, kh, kw, sh, sw, int(transposed))
 
 
 def conv_c1_stat_rows(nimg, H, W, Cout, stride) -> int:

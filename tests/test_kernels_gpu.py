@@ -70,7 +70,7 @@ def test_conv2d_forward_stats(cin, cout, k, s, p, H):
     xv = to_view(x)
     Ho, Wo = ref.shape[-2:]
     yv = ops.new_view(3, Ho, Wo, cout)
-    rows = ops.conv2d_stat_rows(3, Ho, Wo, cout)
+    rows = ops.conv2d_stat_rows(3, Ho, Wo, cin, cout, k[0], k[1], s, s)
     stats = torch.full((rows, 2, cout), float("nan"), device=DEV)        # every row must be overwritten
     ops.conv2d(xv, pack(w), yv, k[0], k[1], s, s, p[0], p[1], stats=stats)
     close(from_view(yv), ref, what="y")
@@ -133,7 +133,7 @@ def test_conv2d_transposed(cin, cout, k, s, p, H, op):
     Ho, Wo = ref.shape[-2:]
     yv = ops.new_view(2, Ho, Wo, cout)
     wp = pack(w.permute(1, 0, 2, 3))                                      # -> [Cout][kh][kw][Cin]
-    rows = ops.conv2d_stat_rows(2, Ho, Wo, cout, s, s, True)
+    rows = ops.conv2d_stat_rows(2, Ho, Wo, cin, cout, k[0], k[1], s, s, True)
     stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
     ops.conv2d(to_view(x), wp, yv, k[0], k[1], s, s, p[0], p[1], transposed=True, stats=stats)
     close(from_view(yv), ref, what="y")
@@ -195,7 +195,7 @@ def test_conv2d_fused_activation_backward_and_bias_sums(cin, cout, s, slope, acc
     old = r(N, cout, Ho, Ho, seed=44)
     ref = (dx + (old if acc else 0)) * torch.where(yact > 0, 1.0, slope)
     yv = to_view(old)
-    rows = ops.conv2d_stat_rows(N, Ho, Ho, cout, s, s, True)
+    rows = ops.conv2d_stat_rows(N, Ho, Ho, cin, cout, 3, 3, s, s, True)
     stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
     ops.conv2d(to_view(g), pack(w.permute(1, 0, 2, 3)), yv, 3, 3, s, s, 1, 1, transposed=True, accumulate=acc,
                mask=to_view(yact), mask_slope=slope, stats=stats, stats_post=True)
