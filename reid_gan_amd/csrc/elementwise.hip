@@ -243,10 +243,33 @@ __global__ __launch_bounds__(ROWRED_THREADS) void bn_finalize_kernel(
   if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
 }
 
+// fold[r'][j] = sum over rows r = r' (mod FOLD_ROWS) of stats[r][j], j < 2C: with tens of thousands of partial
+// rows (512x512 inference) one block per 32 channels would crawl through them alone.
+#define FOLD_ROWS 256
+__global__ __launch_bounds__(256) void rows_fold_kernel(const float* __restrict__ stats, int nrows, int W2,
+                                                        float* __restrict__ fold) {
+  const int j = blockIdx.x * 256 + threadIdx.x, rp = blockIdx.y;
+  if (j >= W2) return;
+  float a = 0.f;
+#pragma unroll 4
+  for (int r = rp; r < nrows; r += FOLD_ROWS) a += stats[(long long)r * W2 + j];
+  fold[(long long)rp * W2 + j] = a;
+}
+
+// fold: NULL, or fp32 scratch [ried_bn_finalize_fold_floats(C)]; with it, more than 4 * FOLD_ROWS partial rows are
+// first folded down to FOLD_ROWS by a wide kernel.
+extern "C" long long ried_bn_finalize_fold_floats(int C) { return (long long)FOLD_ROWS * 2 * C; }
+
 extern "C" int ried_bn_finalize(const float* stats, int nrows, int C, long long count, float eps, float momentum,
                                 float* save, float* running_mean, float* running_var,
-                                long long* num_batches_tracked, hipStream_t stream) {
+                                long long* num_batches_tracked, float* fold, hipStream_t stream) {
   RIED_CHECK_ARG(stats && save && C > 0 && count > 0 && nrows > 0, "ried_bn_finalize: bad arguments");
+  if (fold && nrows > 4 * FOLD_ROWS) {
+    hipLaunchKernelGGL(rows_fold_kernel, dim3(ceil_div(2 * C, 256), FOLD_ROWS), dim3(256), 0, stream, stats, nrows,
+                       2 * C, fold);
+    stats = fold;
+    nrows = FOLD_ROWS;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(ROWRED_THREADS), 0, stream, stats, nrows, C,
                      (float)count, eps, momentum, save, running_mean, running_var, num_batches_tracked);
   RIED_CHECK_LAUNCH("ried_bn_finalize");

@@ -723,7 +723,7 @@ static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int kstep
   const int cus = 256;
   const int slots128 = cus * (t.bm == 128 ? 2 : 3), slots64 = cus * (t.bm == 128 ? 3 : 5);
   const double cost128 = (double)ceil_div(b128, slots128) * 1.0, cost64 = (double)ceil_div(b64, slots64) * 0.62;
-  t.bn = cost128 <= cost64 ? 128 : 64;
+  t.bn = (cost128 <= cost64 || b128 >= 4 * slots128) ? 128 : 64;     // many rounds: the larger tile's reuse wins
   // Small grids (measured: every layer on 4x4 maps, and 8x8 maps with few output channels): 64x64 tiles put
   // twice as many blocks on the chip and win by 15-25 %; with a long K loop and at most two blocks per CU
   // anyway, four LDS stages hide the per-step latency.

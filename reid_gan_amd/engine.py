@@ -412,6 +412,8 @@ class ConvBN:
         self.counters = torch.zeros(2, dtype=torch.int32, device=ctx.device)    # last-block tickets: fwd, bwd
         self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, cin, c.cout, c.kh, c.kw, c.sh, c.sw, deconv)
         ctx.stats(self, "stats", self.stat_rows * 2 * cout)
+        self.fold = (torch.empty(ops.bn_finalize_fold_floats(cout), dtype=F32, device=ctx.device)
+                     if self.stat_rows > 1024 else None)
         self.draw: Optional[View] = None
         if ctx.grads:
             ctx.need_f32(ops.bn_backward_scratch_floats(cout))
@@ -431,7 +433,7 @@ class ConvBN:
             c.conv(self.raw, stats=self.stats)
             ops.bn_finalize(self.stats, self.stat_rows, c.cout, self.raw.npix, self.save,
                             st.b[self.bn + ".running_mean"],
-                            st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"])
+                            st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"], fold=self.fold)
         else:
             c.conv(self.raw)
             ops.bn_eval_stats(st.b[self.bn + ".running_mean"], st.b[self.bn + ".running_var"], c.cout, self.save)
@@ -472,6 +474,8 @@ class ConvBNC1:
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
         self.stat_rows = ops.conv_c1_stat_rows(N, H, W, cout, 2)
         ctx.stats(self, "stats", self.stat_rows * 2 * cout)
+        self.fold = (torch.empty(ops.bn_finalize_fold_floats(cout), dtype=F32, device=ctx.device)
+                     if self.stat_rows > 1024 else None)
         if ctx.grads:
             ctx.need_f32(ops.bn_backward_scratch_floats(cout))
             ctx.need_f32(ops.conv_c1_wgrad_scratch_floats(cout))
@@ -485,7 +489,7 @@ class ConvBNC1:
         if ctx.training:
             ops.conv_c1_fwd(x, w, self.raw, 2, stats=self.stats)
             ops.bn_finalize(self.stats, self.stat_rows, self.cout, self.raw.npix, self.save, st.b[bn + ".running_mean"],
-                            st.b[bn + ".running_var"], st.b[bn + ".num_batches_tracked"])
+                            st.b[bn + ".running_var"], st.b[bn + ".num_batches_tracked"], fold=self.fold)
         else:
             ops.conv_c1_fwd(x, w, self.raw, 2)
             ops.bn_eval_stats(st.b[bn + ".running_mean"], st.b[bn + ".running_var"], self.cout, self.save)

@@ -233,8 +233,13 @@ def colsum_scratch_floats(C) -> int:
     return lib.ried_colsum_scratch_floats(C)
 
 
-def bn_finalize(stats, nrows, C, count, save, rm=None, rv=None, nbt=None, eps=1e-5, momentum=0.1):
-    lib.ried_bn_finalize(_p(stats), nrows, C, count, eps, momentum, _p(save), _p(rm), _p(rv), _p(nbt), _stream())
+def bn_finalize_fold_floats(C) -> int:
+    return lib.ried_bn_finalize_fold_floats(C)
+
+
+def bn_finalize(stats, nrows, C, count, save, rm=None, rv=None, nbt=None, eps=1e-5, momentum=0.1, fold=None):
+    lib.ried_bn_finalize(_p(stats), nrows, C, count, eps, momentum, _p(save), _p(rm), _p(rv), _p(nbt), _p(fold),
+                         _stream())
 
 
 def bn_eval_stats(rm, rv, C, save, eps=1e-5):

@@ -100,6 +100,20 @@ def test_conv2d_forward_stats(cin, cout, k, s, p, H):
     close(rv.cpu(), 0.81 + 0.19 * v, 3e-3, "running var after two steps")
 
 
+def test_bn_finalize_folds_many_rows():
+    """Thousands of partial rows (512x512 inference) go through the two-step reduction: same statistics."""
+    g = torch.Generator().manual_seed(3)
+    rows, C = 5000, 40
+    stats = torch.rand(rows, 2, C, generator=g).to(DEV)
+    stats[:, 1] += 1.0                                            # keeps the variance positive
+    a, b = torch.empty(2, C, device=DEV), torch.empty(2, C, device=DEV)
+    ops.bn_finalize(stats, rows, C, rows, a)
+    fold = torch.full((ops.bn_finalize_fold_floats(C),), float("nan"), device=DEV)
+    ops.bn_finalize(stats, rows, C, rows, b, fold=fold)
+    close(b.cpu(), a.cpu(), 1e-5, "folded vs direct")
+    close(a[0].cpu(), stats[:, 0].sum(0).cpu() / rows, 1e-5, "mean")
+
+
 def test_conv2d_bias_act_slice_accumulate():
     x = r(2, 64, 8, 8, seed=3)
     w = r(128, 64, 3, 3, seed=4, scale=0.05)
