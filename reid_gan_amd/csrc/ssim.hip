@@ -48,18 +48,32 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
   const long long ibase = (long long)n * H * W;
   const float* imgs[3] = {ia, NIMG == 3 ? ib : ir, ir};
 
-  for (int i = threadIdx.x; i < TIN * TIN; i += 256) {
-    int yy = i / TIN, xx = i - yy * TIN;
-    int gy = y0 + yy, gx = x0 + xx;
-    bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+  {
+    // every global load of the halo tile is issued before the first LDS store, so that the block pays the
+    // memory latency once instead of once per pass of the loop
+    constexpr int NL = (TIN * TIN + 255) / 256;
+    float v[NL][NIMG];
 #pragma unroll
-    for (int k = 0; k < NIMG; ++k) {
-      float v = 0.f;
-      if (ok) {
-        v = imgs[k][ibase + (long long)gy * W + gx];
-        if (do_clamp) v = clampf(v, lo, hi);
+    for (int j = 0; j < NL; ++j) {
+      int i = threadIdx.x + 256 * j;
+      int yy = i / TIN, xx = i - yy * TIN;
+      int gy = y0 + yy, gx = x0 + xx;
+      bool ok = i < TIN * TIN && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
+      long long off = ok ? ibase + (long long)gy * W + gx : ibase;
+#pragma unroll
+      for (int k = 0; k < NIMG; ++k) {
+        float t = imgs[k][off];
+        if (do_clamp) t = clampf(t, lo, hi);
+        v[j][k] = ok ? t : 0.f;
       }
-      tin[k * TIN * TIN + i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      int i = threadIdx.x + 256 * j;
+      if (i < TIN * TIN) {
+#pragma unroll
+        for (int k = 0; k < NIMG; ++k) tin[k * TIN * TIN + i] = v[j][k];
+      }
     }
   }
   __syncthreads();
