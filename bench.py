@@ -48,14 +48,23 @@ def instrumented_step(ts):
     rec = []
     orig = {k: getattr(ops, k) for k in ("conv2d", "conv2d_wgrad", "bgemm")}
 
-    def wrap(name, fn, flops):
+    def wrap(name, fn, flops, nbytes=None):
         def inner(*a, **kw):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             fn(*a, **kw)
             e1.record()
-            rec.append((name, flops(*a, **kw), e0, e1))
+            rec.append((name, flops(*a, **kw), e0, e1, nbytes(*a, **kw) if nbytes else 0.0))
         return inner
+
+    def b_conv(x, w, y, kh, kw_, sh, sw, ph, pw, accumulate=False, y2=None, mask=None, **k):
+        """Algorithmic HBM bytes of one launch: each operand once (bf16), the fp32 tap copy, re-read on accumulate."""
+        b = 2.0 * (x.npix * x.C + w.numel() + y.npix * y.C * (2 if accumulate else 1))
+        if y2 is not None:
+            b += 4.0 * y.npix * y.C
+        if mask is not None:
+            b += 2.0 * y.npix * y.C
+        return b
 
     def f_conv(x, w, y, kh, kw_, sh, sw, ph, pw, transposed=False, **k):
         if transposed:
@@ -68,21 +77,34 @@ def instrumented_step(ts):
     def f_bgemm(A, lda, bsa, a_tr, B, ldb, bsb, b_tr, M, N, K, batch, *a, **k):
         return 2.0 * M * N * K * batch
 
-    ops.conv2d = wrap("conv", orig["conv2d"], f_conv)
+    ops.conv2d = wrap("conv", orig["conv2d"], f_conv, b_conv)
     ops.conv2d_wgrad = wrap("wgrad", orig["conv2d_wgrad"], f_wgrad)
     ops.bgemm = wrap("bgemm", orig["bgemm"], f_bgemm)
+    launch_jobs = ops.WgradJobs.launch           # the grouped weight-gradient launches of the generator
+    ops.WgradJobs.launch = wrap("wgrad", launch_jobs, lambda self: self.flops)
+    # kernels timed one at a time: no side streams while the events are in place
+    saved = (ts.overlap_vgg, ts.overlap_gbwd, os.environ.get("RIED_SERIAL_BRANCHES"))
+    ts.overlap_vgg = ts.overlap_gbwd = False
+    os.environ["RIED_SERIAL_BRANCHES"] = "1"
     try:
         ts._run_eager()
         torch.cuda.synchronize()
     finally:
         for k, v in orig.items():
             setattr(ops, k, v)
+        ops.WgradJobs.launch = launch_jobs
+        ts.overlap_vgg, ts.overlap_gbwd = saved[0], saved[1]
+        if saved[2] is None:
+            del os.environ["RIED_SERIAL_BRANCHES"]
+        else:
+            os.environ["RIED_SERIAL_BRANCHES"] = saved[2]
     fam = {}
-    for name, fl, e0, e1 in rec:
-        d = fam.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0})
+    for name, fl, e0, e1, nb in rec:
+        d = fam.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
         d["launches"] += 1
         d["flops"] += fl
         d["ms"] += e0.elapsed_time(e1)
+        d["bytes"] += nb
     return fam
 
 
@@ -204,11 +226,18 @@ def main():
         fam = instrumented_step(ts)
         dom = max(fam, key=lambda k: fam[k]["ms"])
         a = fam[dom]["flops"] / (fam[dom]["ms"] * 1e-3)
-        names = {"conv": "igemm_kernel<*, PLAIN_K, GATHER_K> (conv forward / data gradient)",
-                 "wgrad": "igemm_kernel<*, GATHER_TR, PLAIN_TR> (weight gradient)",
+        names = {"conv": "conv_glds_kernel<*> (conv / transposed conv forward and data gradient)",
+                 "wgrad": "igemm_kernel / igemm_jobs_kernel<*, GATHER_TR, PLAIN_TR> (weight gradient)",
                  "bgemm": "igemm_kernel<*, PLAIN_*, PLAIN_*> (attention products)"}
+        # HBM bytes per launch of the conv family from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the
+        # gfx950 correction for wide reads, + WRITE_SIZE); the algorithmic bytes per launch are reported beside it
+        traffic = None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_conv_traffic.json")
+        if dom == "conv" and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["traffic_MB_per_launch"] * 1e6
         out["roofline"] = {"bound": "mfma", "kernel": names[dom], "achieved": a / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
-                           "unit": "TFLOP/s", "frac": a / PEAK_MFMA_BF16, "traffic": None,
+                           "unit": "TFLOP/s", "frac": a / PEAK_MFMA_BF16, "traffic": traffic,
+                           "algorithmic_bytes_per_launch": fam[dom]["bytes"] / fam[dom]["launches"],
                            "launches_per_step": fam[dom]["launches"], "ms_per_step": fam[dom]["ms"],
                            "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}

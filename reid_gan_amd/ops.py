@@ -95,6 +95,7 @@ class WgradJobs:
     def __init__(self):
         self.groups = {}           # (bm, bn) -> [records], [block counts]
         self.dev = []
+        self.flops = 0.0           # 2 * pixels * Cg * Cp * taps over all jobs (for reporting)
 
     def add(self, g: View, p: View, kh, kw, sh, sw, ph, pw, slab_ptr: int, splitk: int):
         import numpy as np
@@ -104,6 +105,7 @@ class WgradJobs:
                                        kh, kw, sh, sw, ph, pw, slab_ptr, splitk, tile.ctypes.data, nb.ctypes.data)
         recs, counts = self.groups.setdefault((int(tile[0]), int(tile[1])), ([], []))
         recs.append(rec); counts.append(int(nb[0]))
+        self.flops += 2.0 * p.npix * p.C * g.C * kh * kw
 
     def finalize(self, device):
         import numpy as np
