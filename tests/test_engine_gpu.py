@@ -275,6 +275,30 @@ def test_train_step_vs_oracle(use_graph):
     assert ts.gs.adam_step.item() == 3 and ts.ds.adam_step.item() == 6
 
 
+def test_segmented_graphs_equal_single_graph():
+    """With several ranks the step is captured as graph segments split at the collectives (and the side streams
+    must rejoin before each split).  Here the collectives are stubbed out (identical replicas: the mean over ranks
+    is the identity), so the segmented capture must reproduce the single-graph step."""
+    B, H = 4, 64
+    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
+    x, y = synth_batch(B, H, seed=99)
+    one = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+    seg = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+    seg.world = 2
+    seg._allreduce_mean = lambda t: None
+    for ts in (one, seg):
+        ts.step(x.to(DEV), y.to(DEV))
+        ts.step()
+    torch.cuda.synchronize()
+    assert len(seg.graphs) > 3 and len(one.graphs) == 1
+    seg.world = 1                     # losses() would all-reduce
+    a, b = one.losses(), seg.losses()
+    for k in a:
+        assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
+    assert torch.allclose(one.gs.flat, seg.gs.flat, rtol=0, atol=3e-4)
+    assert torch.allclose(one.ds.flat, seg.ds.flat, rtol=0, atol=1.2e-3)
+
+
 def test_inference_metrics_vs_oracle():
     sd = g_state()
     B, H = 2, 128

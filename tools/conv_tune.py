@@ -8,6 +8,8 @@ from reid_gan_amd._lib import lib
 # (N, H, W, Cin, Cout, kh, kw, stride, transposed, count per step)
 SHAPES = [l.split() for l in open(sys.argv[1]).read().strip().splitlines()] if len(sys.argv) > 1 else None
 CONFIGS = [(128, 128, 2), (128, 64, 2), (64, 128, 2), (64, 64, 2), (64, 64, 4)]
+if os.environ.get("TUNE_CONFIGS"):
+    CONFIGS = [tuple(int(v) for v in c.split("x")) for c in os.environ["TUNE_CONFIGS"].split(",")]
 
 
 def run(N, H, W, Cin, Cout, kh, kw, s, tr, reps=20):
@@ -71,7 +73,6 @@ if __name__ == "__main__":
     if SHAPES is None:
         SHAPES = gather_shapes()
     rows = []
-    SHAPES = [s for s in SHAPES if s[4] > 64 and s[0] * s[1] * s[2] * (s[7] ** 2 if s[8] else 1) // (s[7] ** 2 if not s[8] else 1) <= 32768]
     for sh in SHAPES:
         N, H, W, Cin, Cout, kh, kw, s, tr, cnt = map(int, sh)
         res, fl = run(N, H, W, Cin, Cout, kh, kw, s, tr)
