@@ -72,6 +72,17 @@ __device__ __forceinline__ float block_sum_256(float v, float* sh4) {
   return sh4[0] + sh4[1] + sh4[2] + sh4[3];
 }
 
+// n / d for 0 <= n < 2^30, 0 < d with n / d < 2^21, from a float reciprocal (inv = 1.0f / d) and one
+// correction step: about a fifth of the instructions of the compiler's exact 32-bit division.
+__device__ __forceinline__ int fast_div(int n, int d, float inv, int& rem) {
+  int q = (int)((float)n * inv);
+  int r = n - q * d;
+  if (r < 0) { --q; r += d; }
+  else if (r >= d) { ++q; r -= d; }
+  rem = r;
+  return q;
+}
+
 static inline int ceil_div(long long a, long long b) { return (int)((a + b - 1) / b); }
 static inline int ew_grid(long long n, int per_block, int cap = 4096) {
   long long g = (n + per_block - 1) / per_block;

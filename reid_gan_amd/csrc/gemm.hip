@@ -297,8 +297,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
     long long orow = n;
     if (E.phase_mode) {          // logical (img, hq, wq) of this phase -> physical pixel
       int hw = E.Hq * E.Wq;
-      int img = n / hw, rem = n - img * hw;
-      int hq = rem / E.Wq, wq = rem - hq * E.Wq;
+      int rem, wq;
+      int img = fast_div(n, hw, 1.0f / (float)hw, rem);
+      int hq = fast_div(rem, E.Wq, 1.0f / (float)E.Wq, wq);
       orow = (long long)img * E.HoWo_full + (long long)(hq * E.sh + pa) * E.Wo_full + (wq * E.sw + pb);
     }
 #pragma unroll
@@ -611,12 +612,14 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
     wrow[i] = m < P.M ? (unsigned)m * (unsigned)P.A.ld * 2u : GLDS_OOB;      // stays out of range after + wk: wk < 2^28
   }
   int gy[NLB], gx[NLB], pix[NLB];
+  const int hw = X.Ho * X.Wo;
+  const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)X.Wo;
 #pragma unroll
   for (int i = 0; i < NLB; ++i) {
     int n = n0 + i * 32 + rowp;
-    int hw = X.Ho * X.Wo;
-    int img = n / hw, rem = n - img * hw;
-    int oy = rem / X.Wo, ox = rem - oy * X.Wo;
+    int rem, ox;
+    int img = fast_div(n, hw, inv_hw, rem);
+    int oy = fast_div(rem, X.Wo, inv_wo, ox);
     if (X.transposed) { gy[i] = oy + (pa + X.ph - r0) / X.sh; gx[i] = ox + (pb + X.pw - s0) / X.sw; }
     else              { gy[i] = oy * X.sh - X.ph;             gx[i] = ox * X.sw - X.pw; }
     pix[i] = (img * X.H + gy[i]) * X.W + gx[i];
@@ -661,23 +664,22 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
 
   const int frow = (lane & 15) * 128;
   const int sw0 = (((lane >> 4)) ^ (lane & 7)) << 4, sw1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
-  auto compute = [&](int buf) {
+  bf16x8_t fa[2][TM], fb[2][TN];
+  auto load_frags = [&](int buf, int ks) {
     const char* sa = smem + buf * STAGE + wm * (BM / 2) * 128 + frow;
     const char* sb = smem + buf * STAGE + BM * 128 + wn * (BN / 2) * 128 + frow;
+    const int sw = ks ? sw1 : sw0;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int sw = ks ? sw1 : sw0;
-      bf16x8_t fa[TM], fb[TN];
+    for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + sw);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + sw);
+    for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 2048 + sw);
+  };
+  auto mfmas = [&](int ks) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 2048 + sw);
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    }
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
   };
 
   // prologue: NST-1 stages in flight (stages past the end of K fetch zeros: uniform counts)
@@ -689,8 +691,11 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
     // the barrier extends that to every wave's loads and retires all reads of the buffer refilled next
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NLA + NLB)) : "memory");
     __builtin_amdgcn_s_barrier();
+    load_frags(rd, 0);          // the LDS reads of the first k-slice fly while the next stage's addresses are built
     issue(wr);
-    compute(rd);
+    load_frags(rd, 1);
+    mfmas(0);
+    mfmas(1);
     rd = rd + 1 == NST ? 0 : rd + 1;
     wr = wr + 1 == NST ? 0 : wr + 1;
   }
