@@ -56,6 +56,16 @@ int ried_conv2d_bn(const void* x, long long ldx, const void* w, void* y, long lo
                    int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
                    float* stats, unsigned* counter, float eps, float momentum, float* save, float* running_mean,
                    float* running_var, long long* num_batches_tracked, ried_stream_t stream);
+/* A tap layer of the perceptual loss on the prediction images (src/loss.py:179-189, VGG16 conv3x3 + bias + ReLU):
+ * y as ried_conv2d would write it, and in the same pass d = y (fp32, before rounding) - target (the same tap of the
+ * target images, fp32 [npix][ld_target]); stats rows (as ried_conv2d) receive the column sums of d and d*d,
+ * gout [npix][ld_gout] (bf16) = gscale * d.  Replaces F.mse_loss on the two feature maps and its backward. */
+int ried_conv2d_tap_mse(const void* x, long long ldx, const void* w, const float* bias, void* y, long long ldy,
+                        int nimg, int H, int W, int Cin, int Cout, const float* target, long long ld_target, void* gout,
+                        long long ld_gout, float gscale, float* stats, ried_stream_t stream);
+/* out[0] += scale * sum over rows and channels of stats[r][which][c] */
+int ried_stat_rows_total(const float* stats, int nrows, int C, int which, float scale, float* out,
+                         ried_stream_t stream);
 /* out[c] += sum over rows of stats[r][0][c] (stats: [nrows][2][C], as written by ried_conv2d) */
 int ried_stat_rows_sum(const float* stats, int nrows, int C, float* out, ried_stream_t stream);
 

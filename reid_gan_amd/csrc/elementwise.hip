@@ -859,6 +859,36 @@ __global__ __launch_bounds__(ROWRED_THREADS) void stat_rows_sum_kernel(const flo
     else atomicAdd(&out[c], t);           // a handful of adders per address
   }
 }
+// out[0] += scale * sum over rows r and channels c of stats[r][which][c]
+__global__ __launch_bounds__(1024) void stat_rows_total_kernel(const float* __restrict__ stats, int nrows, int C,
+                                                               int which, float scale, float* __restrict__ out) {
+  __shared__ float sh[16];
+  const long long total = (long long)nrows * C;
+  float a = 0.f;
+#pragma unroll 4
+  for (long long i = blockIdx.x * 1024ll + threadIdx.x; i < total; i += gridDim.x * 1024ll) {
+    long long r = i / C;
+    a += stats[(r * 2 + which) * C + (i - r * C)];
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t += sh[k];
+    atomicAdd(out, t * scale);
+  }
+}
+extern "C" int ried_stat_rows_total(const float* stats, int nrows, int C, int which, float scale, float* out,
+                                    hipStream_t stream) {
+  RIED_CHECK_ARG(stats && out && nrows > 0 && C > 0 && (which == 0 || which == 1), "ried_stat_rows_total: bad arguments");
+  hipLaunchKernelGGL(stat_rows_total_kernel, dim3(ew_grid((long long)nrows * C, 4096, 32)), dim3(1024), 0, stream,
+                     stats, nrows, C, which, scale, out);
+  RIED_CHECK_LAUNCH("ried_stat_rows_total");
+  return RIED_OK;
+}
+
 // out[c] += sum_r stats[r][0][c]; stats: [nrows][2][C] partial rows written by a conv epilogue
 extern "C" int ried_stat_rows_sum(const float* stats, int nrows, int C, float* out, hipStream_t stream) {
   RIED_CHECK_ARG(stats && out && nrows > 0 && C > 0, "ried_stat_rows_sum: bad arguments");

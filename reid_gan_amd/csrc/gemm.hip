@@ -55,6 +55,11 @@ struct GemmEpilogue {
   float mask_slope;
   int stats_post;          // stats = column sums of the final values (bias gradient) instead of the raw results
   BnFinalize fin;          // fin.counter != null: the last block to finish turns the stats rows into BN statistics
+  const float* sub;        // perceptual-loss tap: d = value - sub[row][m] (the target's features, fp32);
+  long long ld_sub;        //   stats rows = column sums of d and d*d, gout[row][m] = gscale * d (the seed of the
+  bf16_t* gout;            //   tap's gradient); the value itself is still stored as the layer's output
+  long long ld_gout;
+  float gscale;
   int phase_mode, Wo_full, HoWo_full, Hq, Wq, sh, sw;   // logical row -> physical pixel
 };
 
@@ -308,7 +313,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
       float v[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q] * E.alpha;
-      if (E.stats && !E.stats_post) {
+      if (E.stats && !E.stats_post && !E.sub) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { ssum[i][q] += v[q]; ssq[i][q] += v[q] * v[q]; }
       }
@@ -331,6 +336,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
         v[2] = gam * v[2] + bflo(rr[1]); v[3] = gam * v[3] + bfhi(rr[1]);
       }
       if (E.out2) *reinterpret_cast<f32x4*>(E.out2 + orow * E.ldc2 + m) = f32x4{v[0], v[1], v[2], v[3]};
+      if (E.sub) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(E.sub + orow * E.ld_sub + m);
+        float d[4] = {v[0] - t[0], v[1] - t[1], v[2] - t[2], v[3] - t[3]};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ssum[i][q] += d[q]; ssq[i][q] += d[q] * d[q]; }
+        *reinterpret_cast<u32x2*>(E.gout + orow * E.ld_gout + m) =
+            u32x2{pack2bf(E.gscale * d[0], E.gscale * d[1]), pack2bf(E.gscale * d[2], E.gscale * d[3])};
+      }
       long long off = obase + orow * E.ldc + m;
       if (E.accumulate) {
         if (E.out_f32) {
@@ -777,7 +790,8 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                        int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
                        int transposed, const float* bias, int act, float* stats, int accumulate, int out_f32,
                        float* y2, long long ldy2, const void* mask, long long ldmask, float mask_slope,
-                       int stats_post, const BnFinalize* fin, hipStream_t stream) {
+                       int stats_post, const BnFinalize* fin, hipStream_t stream, const float* sub = nullptr,
+                       long long ld_sub = 0, void* gout = nullptr, long long ld_gout = 0, float gscale = 0.f) {
   RIED_CHECK_ARG(x && w && y, "ried_conv2d: null pointer");
   RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
   RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
@@ -820,6 +834,10 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   P.E.out2 = y2; P.E.ldc2 = ldy2;
   RIED_CHECK_ARG(!mask || (ldmask % 4 == 0 && ldmask >= Cout && ((uintptr_t)mask % 8) == 0), "ried_conv2d: bad mask view");
   P.E.mask = (const bf16_t*)mask; P.E.ld_mask = ldmask; P.E.mask_slope = mask_slope; P.E.stats_post = stats_post;
+  RIED_CHECK_ARG(!sub || (stats && gout && ld_sub % 4 == 0 && ld_gout % 4 == 0 && ((uintptr_t)sub % 16) == 0 &&
+                          ((uintptr_t)gout % 8) == 0),
+                 "ried_conv2d: bad perceptual-tap arguments");
+  P.E.sub = sub; P.E.ld_sub = ld_sub; P.E.gout = (bf16_t*)gout; P.E.ld_gout = ld_gout; P.E.gscale = gscale;
   long long a_bytes = (long long)Cout * kh * kw * Cin * 2;
   long long b_bytes = (((long long)nimg * H * W - 1) * ldx + Cin) * 2;
   RIED_CHECK_ARG(a_bytes < (long long)GLDS_OOB - (1 << 28) && b_bytes < (long long)GLDS_OOB,
@@ -900,6 +918,20 @@ static int wgrad_params(GemmParams& P, const void* g, long long ldg, int Cg, int
   P.tiles_m = ceil_div(Cg, bm);
   P.grid[0] = P.tiles_m * ceil_div(Cp, bn); P.grid[1] = kh * kw; P.grid[2] = splitk;
   return RIED_OK;
+}
+
+// A VGG16 tap layer of the perceptual loss on the PREDICTION images (src/loss.py:179-189): y = relu(conv3x3(x) + bias)
+// as usual, and in the same pass d = y(fp32, before rounding) - target (the same tap of the target images, fp32
+// [npix][ld_target]); stats rows [rows][2][Cout] receive the column sums of d and d*d (rows as for ried_conv2d:
+// sum of the second halves / count = the tap's MSE), and gout [npix][ld_gout] = gscale * d, the seed of the tap's
+// gradient.  No fp32 copy of the prediction's features is written or re-read.
+extern "C" int ried_conv2d_tap_mse(const void* x, long long ldx, const void* w, const float* bias, void* y,
+                                   long long ldy, int nimg, int H, int W, int Cin, int Cout, const float* target,
+                                   long long ld_target, void* gout, long long ld_gout, float gscale, float* stats,
+                                   hipStream_t stream) {
+  RIED_CHECK_ARG(target && gout && stats, "ried_conv2d_tap_mse: null pointer");
+  return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, 0, bias, 1, stats, 0, 0,
+                     nullptr, 0, nullptr, 0, 0.f, 0, nullptr, stream, target, ld_target, gout, ld_gout, gscale);
 }
 
 // Weight gradient partial sums.  g: the tensor that is gathered through the kernel window

@@ -1105,6 +1105,7 @@ class Vgg:
             else:
                 nxt = Slot(ctx.act(N, h, w, v))
                 core = ConvCore(ctx, f"{idx}.weight", cin, v, 3, 1, 1, False, cur, True, need_wgrad=False)
+                cin_prev = cin
                 wt = weights[f"{idx}.weight"].to(dev, F32).contiguous()
                 ops.pack_weight(wt, core.wp, v, 3, 3, cin, cin * 9, 3, 1, 9)
                 if grads:
@@ -1115,6 +1116,8 @@ class Vgg:
                 if idx - 1 in VGG_TAPS:        # taps are also kept in fp32: the loss is a small difference
                     tap32 = torch.empty(N, h, w, v, dtype=F32, device=dev)
                     self.taps.append((nxt, tap32))
+                    core.mse_rows = ops.conv2d_stat_rows(B, h, w, cin_prev, v, 3, 3)      # the fused prediction pass
+                    ctx.stats(core, "mse_stats", core.mse_rows * 2 * v)
                 self.layers.append(("conv", core, weights[f"{idx - 2}.bias"].to(dev, F32).contiguous(), nxt, tap32,
                                     cur_is_conv, cur_is_tap))
                 cur_is_conv, cur_is_tap = True, tap32 is not None
@@ -1138,6 +1141,35 @@ class Vgg:
                 _, core, bias, out, tap32 = l[:5]
                 ops.conv2d(core.xin.images(n0, n1).v, core.wp, out.images(n0, n1).v, 3, 3, 1, 1, 1, 1, bias=bias, act=1,
                            y2=None if tap32 is None else tap32[n0:n1])
+
+    def forward_pred_fused(self, imgs: torch.Tensor, weight: float):
+        """The prediction half (images [0, B)) with the perceptual MSE against the target half's fp32 taps (which
+        forward(imgs, B, 2B) must have produced) fused into the tap layers: no fp32 copy of the prediction's
+        features, no separate loss kernels.  Seeds each tap's gradient with weight * d loss / d tap; follow with
+        loss_from_rows() and backward()."""
+        B = self.B
+        a0 = self.a0.images(0, B)
+        ops.conv_c1_fwd(imgs[0:B], self.w0, a0.v, 1, bias=self.b0, in_scale=1.0 / 4096.0, in_shift=0.25, act=1)
+        for l in self.layers:
+            if l[0] == "pool":
+                p = l[1]
+                ops.pool_fwd(p.xin.images(0, B).v, p.out.images(0, B).v, p.mode)
+                continue
+            _, core, bias, out, tap32 = l[:5]
+            o = out.images(0, B)
+            if tap32 is None:
+                ops.conv2d(core.xin.images(0, B).v, core.wp, o.v, 3, 3, 1, 1, 1, 1, bias=bias, act=1)
+            else:
+                n = o.v.npix * o.v.C
+                ops.conv2d_tap_mse(core.xin.images(0, B).v, core.wp, bias, o.v, tap32[B:], o.g,
+                                   2.0 * weight / (n * len(self.taps)), core.mse_stats)
+
+    def loss_from_rows(self, loss: torch.Tensor):
+        """loss[0] += mean over taps of MSE(tap(pred), tap(target)) from the rows forward_pred_fused() left."""
+        for l in self.layers:
+            if l[0] == "conv" and l[4] is not None:
+                core, v = l[1], l[3].images(0, self.B).v
+                ops.stat_rows_total(core.mse_stats, core.mse_rows, v.C, 1, 1.0 / (v.npix * v.C * len(self.taps)), loss)
 
     def loss_and_seed(self, loss: torch.Tensor, weight: float):
         """loss[0] += mean over taps of MSE(tap(pred), tap(target)); seeds each tap's gradient (prediction

@@ -78,6 +78,19 @@ def conv2d(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed
                     _stream())
 
 
+def conv2d_tap_mse(x: View, w: torch.Tensor, bias: torch.Tensor, y: View, target: torch.Tensor, gout: View,
+                   gscale: float, stats: torch.Tensor):
+    """VGG tap layer on the prediction images with the perceptual MSE against `target` (fp32, same shape as y,
+    contiguous) fused: stats rows get sum(d), sum(d*d) per channel, gout = gscale * d."""
+    lib.ried_conv2d_tap_mse(x.ptr, x.ld, _p(w), _p(bias), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.C, _p(target), y.C,
+                            gout.ptr, gout.ld, gscale, _p(stats), _stream())
+
+
+def stat_rows_total(stats: torch.Tensor, nrows: int, C: int, which: int, scale: float, out: torch.Tensor):
+    """out[0] += scale * sum over rows and channels of stats[r][which][c]."""
+    lib.ried_stat_rows_total(_p(stats), nrows, C, which, scale, _p(out), _stream())
+
+
 def stat_rows_sum(stats: torch.Tensor, nrows: int, C: int, out: torch.Tensor):
     """out[c] += sum over the rows of stats[r][0][c]."""
     lib.ried_stat_rows_sum(_p(stats), nrows, C, _p(out), _stream())

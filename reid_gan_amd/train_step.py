@@ -131,12 +131,12 @@ class TrainStep:
         sc[SC_VGG:SC_SSIM + 1].zero_()
         # perceptual term (loss.py:179-189); the target half of the features was started in _body()
         self.v_in[:B].copy_(pred)
-        self.V.forward(self.v_in, 0, B)
         if self._vgg_side is not None:
             self._join(self._vgg_side)
             self._vgg_side = None
         self.V.ctx.zero_backward()
-        self.V.loss_and_seed(sc[SC_VGG:], self.wv)
+        self.V.forward_pred_fused(self.v_in, self.wv)      # the MSE against the target taps rides in the tap layers
+        self.V.loss_from_rows(sc[SC_VGG:])
         self.V.backward(self.dpred)
         # DSSIM term on raw HU (loss.py:191): ssim(target, pred), gradient to pred
         self.ssim_sums.zero_()

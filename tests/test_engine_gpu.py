@@ -214,6 +214,16 @@ def test_vgg_taps_and_perceptual_gradient():
     V.backward(dimg)
     assert abs(loss.item() - vl.item()) <= 2e-2 * vl.item(), (loss.item(), vl.item())
     grad_close(dimg.cpu(), gref, "d perceptual / d pred", cos=0.98, ratio=0.08)
+    # the fused route of the training step: target half first, then the prediction half with the MSE in the taps
+    imgs = torch.cat([pred, y], 0).to(DEV)
+    V.forward(imgs, B, 2 * B)
+    V.forward_pred_fused(imgs, 0.3)
+    loss2 = torch.zeros(1, device=DEV)
+    V.loss_from_rows(loss2)
+    dimg2 = torch.zeros(B, 1, H, H, device=DEV)
+    V.backward(dimg2)
+    assert abs(loss2.item() - loss.item()) <= 2e-3 * loss.item(), (loss2.item(), loss.item())
+    grad_close(dimg2.cpu(), dimg.cpu(), "fused vs separate perceptual gradient", cos=0.999, ratio=0.01)
 
 
 @pytest.mark.parametrize("use_graph", [False, True])
