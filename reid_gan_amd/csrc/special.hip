@@ -141,18 +141,21 @@ extern "C" int ried_conv_c1_stat_rows(int nimg, int H, int W, int Cout, int stri
 }
 
 // part[block][co][t] = sum over the block's pixels of dy[p][co] * xaff[p@t]; a second kernel adds the rows into dw.
-// Tiles of 256 pixels: the dy tile is staged through LDS with coalesced 16-byte loads and each thread computes the
-// 9 taps of one pixel; then wave w accumulates channels [w*COUT/4, (w+1)*COUT/4) for all 256 pixels, one pixel
-// per lane and pass, in registers.  The lanes are summed once, after the block's last tile.
+// Tiles of 256 pixels, 8 waves: the dy tile is staged through LDS with coalesced 16-byte loads and the first four
+// waves compute the 9 taps of one pixel each; then wave w accumulates channels [w*COUT/8, (w+1)*COUT/8) for all 256
+// pixels, one pixel per lane and pass, in registers (72 accumulators at COUT = 64, so that four waves fit a SIMD
+// and the loads of one block hide behind the arithmetic of another).  The lanes are summed once, after the block's
+// last tile.
+#define C1_WG_THREADS 512
 template <int COUT>
-__global__ __launch_bounds__(C1_TILE) void conv_c1_wgrad_kernel(const float* __restrict__ x,
-                                                                const bf16_t* __restrict__ dy, long long lddy,
-                                                                int nimg, int H, int W, int Ho, int Wo, int stride,
-                                                                float in_scale, float in_shift,
-                                                                float* __restrict__ part) {
+__global__ __launch_bounds__(C1_WG_THREADS, 4) void conv_c1_wgrad_kernel(const float* __restrict__ x,
+                                                                          const bf16_t* __restrict__ dy, long long lddy,
+                                                                          int nimg, int H, int W, int Ho, int Wo,
+                                                                          int stride, float in_scale, float in_shift,
+                                                                          float* __restrict__ part) {
   constexpr int ROWB = COUT * 2 + 16;
   constexpr int CC = COUT / 8;
-  constexpr int CPW = COUT / 4;                       // channels per wave
+  constexpr int CPW = COUT / 8;                       // channels per wave: 8 or 4
   __shared__ __attribute__((aligned(16))) char tile[C1_TILE * ROWB];
   __shared__ float xs[9][C1_TILE];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -167,28 +170,29 @@ __global__ __launch_bounds__(C1_TILE) void conv_c1_wgrad_kernel(const float* __r
     const long long p0 = (long long)tl * C1_TILE;
     __syncthreads();                                  // the previous tile has been consumed
 #pragma unroll
-    for (int i = 0; i < CC; ++i) {
-      int j = i * C1_TILE + threadIdx.x;
+    for (int i = 0; i < C1_TILE * CC / C1_WG_THREADS; ++i) {
+      int j = i * C1_WG_THREADS + threadIdx.x;
       int px = j / CC, cc = j - px * CC;
       u32x4 v = u32x4{0, 0, 0, 0};
       if (p0 + px < npix) v = *reinterpret_cast<const u32x4*>(dy + (p0 + px) * lddy + cc * 8);
       *reinterpret_cast<u32x4*>(tile + px * ROWB + cc * 16) = v;
     }
-    float xv[9];
-    c1_taps(x, p0 + threadIdx.x, npix, H, W, Ho, Wo, stride, in_scale, in_shift, xv);
+    if (threadIdx.x < C1_TILE) {
+      float xv[9];
+      c1_taps(x, p0 + threadIdx.x, npix, H, W, Ho, Wo, stride, in_scale, in_shift, xv);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) xs[t][threadIdx.x] = xv[t];
+      for (int t = 0; t < 9; ++t) xs[t][threadIdx.x] = xv[t];
+    }
     __syncthreads();
-#pragma unroll
+#pragma unroll 1
     for (int j = 0; j < C1_TILE / 64; ++j) {
       const int px = lane + 64 * j;
       float g[CPW], xt[9];
-#pragma unroll
-      for (int h = 0; h < CPW / 8; ++h) {
-        float f[8];
-        unpack8s(*reinterpret_cast<const u32x4*>(tile + px * ROWB + (wave * CPW + h * 8) * 2), f);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) g[h * 8 + q] = f[q];
+      if constexpr (CPW == 8) {
+        unpack8s(*reinterpret_cast<const u32x4*>(tile + px * ROWB + wave * 16), g);
+      } else {
+        const u32x2 r = *reinterpret_cast<const u32x2*>(tile + px * ROWB + wave * 8);
+        g[0] = bflo(r[0]); g[1] = bfhi(r[0]); g[2] = bflo(r[1]); g[3] = bfhi(r[1]);
       }
 #pragma unroll
       for (int t = 0; t < 9; ++t) xt[t] = xs[t][px];
@@ -224,7 +228,7 @@ __global__ void rows_add_kernel(const float* __restrict__ part, int nrows, int W
   }
 }
 
-#define C1_WGRAD_MAX_ROWS 512
+#define C1_WGRAD_MAX_ROWS 768
 // dw[Cout][9] += weight gradient.  scratch: fp32 [ried_conv_c1_wgrad_scratch_floats(Cout)].
 extern "C" int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy, int nimg, int H, int W, int Cout,
                                   int stride, float in_scale, float in_shift, float* dw, float* scratch,
@@ -238,10 +242,10 @@ extern "C" int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy
   long long npix = (long long)nimg * Ho * Wo;
   int grid = ew_grid(npix, C1_TILE * 2, C1_WGRAD_MAX_ROWS);
   if (Cout == 32)
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel<32>, dim3(grid), dim3(C1_TILE), 0, stream, x, (const bf16_t*)dy, lddy,
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel<32>, dim3(grid), dim3(C1_WG_THREADS), 0, stream, x, (const bf16_t*)dy, lddy,
                        nimg, H, W, Ho, Wo, stride, in_scale, in_shift, scratch);
   else
-    hipLaunchKernelGGL(conv_c1_wgrad_kernel<64>, dim3(grid), dim3(C1_TILE), 0, stream, x, (const bf16_t*)dy, lddy,
+    hipLaunchKernelGGL(conv_c1_wgrad_kernel<64>, dim3(grid), dim3(C1_WG_THREADS), 0, stream, x, (const bf16_t*)dy, lddy,
                        nimg, H, W, Ho, Wo, stride, in_scale, in_shift, scratch);
   hipLaunchKernelGGL(rows_add_kernel, dim3(ceil_div(Cout * 9, 32)), dim3(256), 0, stream, scratch, grid, Cout * 9, dw);
   RIED_CHECK_LAUNCH("ried_conv_c1_wgrad");
