@@ -42,8 +42,10 @@ int ried_device_cus(void);
  *   mask/ldmask/mask_slope: optional view shaped like y; the final value (after accumulate) is multiplied by
  *   (mask > 0 ? 1 : mask_slope): the backward of the ReLU / LeakyReLU whose output `mask` is (autograd of
  *   src/rinet.py:139,190 and the VGG ReLUs), fused into the data gradient that produces the tensor.
- *   stats_post: the stats rows hold column sums of the FINAL values (sum in [r][0][c]) - the bias gradient of the
- *   layer below (src/rinet.py:137) - instead of the raw results. */
+ *   stats_post = 1: the stats rows hold column sums of the FINAL values (sum in [r][0][c]) - the bias gradient of
+ *   the layer below (src/rinet.py:137) - instead of the raw results.
+ *   stats_post = 2: the raw sums are ADDED (float atomics) into row (tile mod ried_bn_fold_rows()) of a buffer the
+ *   caller zeroed, so that min(rows, ried_bn_fold_rows()) rows hold the totals: the form ried_bn_apply_train reads. */
 int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W, int Cin,
                 int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
                 const float* bias, int act, float* stats, int accumulate, int out_f32, float* y2, long long ldy2,
@@ -131,6 +133,15 @@ int ried_bn_eval_stats(const float* running_mean, const float* running_var, int 
 /* y = [relu](gamma*(x-mean)*invstd + beta) [+ y]   (the residual add of src/rinet.py:250,345,443 is the accumulate) */
 int ried_bn_apply(const void* x, long long ldx, void* y, long long ldy, long long npix, int C, const float* save,
                   const float* gamma, const float* beta, int relu, int accumulate, ried_stream_t stream);
+/* Small layers, one launch fewer (BatchNorm2d train mode, src/rinet.py:187-193,199-205): ried_bn_apply_train =
+ * ried_bn_finalize + ried_bn_apply on stats [nrows][2][C] (nrows <= ried_bn_fold_rows(), written by ried_conv2d with
+ * stats_post = 2; count = npix); the blocks of the apply pass sum the few rows themselves.  The float atomics of
+ * the folding make the sums depend on the order the conv's blocks finish (last-bit differences between runs). */
+int ried_bn_fold_rows(void);
+int ried_bn_apply_train(const void* x, long long ldx, void* y, long long ldy, long long npix, int C,
+                        const float* stats, int nrows, float eps, float momentum, float* save, float* running_mean,
+                        float* running_var, long long* num_batches_tracked, const float* gamma, const float* beta,
+                        int relu, int accumulate, ried_stream_t stream);
 /* dx = d(loss)/d(conv output) from dy = d(loss)/d(bn+relu output); scratch: fp32
  * [ried_bn_backward_scratch_floats(C)] (need not be zeroed); dgamma/dbeta may be NULL; counter: NULL, or one
  * zero-initialised unsigned per layer (left at zero) - the last block of the reduction then finishes the sums. */

@@ -481,6 +481,133 @@ extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, l
 extern "C" long long ried_bn_backward_scratch_floats(int C) { return (long long)(BN_BWD_MAX_ROWS + 1) * 2 * C; }
 
 // ---------------------------------------------------------------------------
+// BatchNorm forward for small layers in one launch after the conv instead of two.  Blocks own a slice of up to 64
+// channels (blockIdx.y) and a group of pixels (blockIdx.x), so that the few folded rows of the statistics can be
+// re-reduced by every block for its own slice (a few KB from L2) instead of by a separate dependent launch.
+// ---------------------------------------------------------------------------
+#define BN_SLICE 64
+#define BN_FOLD_ROWS 32            // rows of the folded forward statistics (atomics of the conv epilogue)
+struct SliceWalk {
+  int c0, CCs, SW;      // first channel of the slice, 8-channel chunks per slice, channels per slice
+  int cl, c;            // this thread's chunk within the slice, its first channel
+  long long p, step;
+  bool active;
+  __device__ __forceinline__ SliceWalk(int C) {
+    CCs = min(BN_SLICE / 8, C >> 3);
+    SW = CCs * 8;
+    c0 = blockIdx.y * BN_SLICE;
+    const int PPB = blockDim.x / CCs, pl = threadIdx.x / CCs;
+    cl = threadIdx.x - pl * CCs;
+    c = c0 + cl * 8;
+    active = pl < PPB && c < C;
+    p = (long long)blockIdx.x * PPB + pl;
+    step = (long long)gridDim.x * PPB;
+  }
+};
+
+// sums[k][ch] (k < 2, ch < SW) = sum over rows of part[r][k][c0 + ch]; part: [nrows][2][C].  256 threads.
+__device__ __forceinline__ void slice_row_sums(const float* __restrict__ part, int nrows, int C, int c0, int SW,
+                                               float* lds /*256*/, float* sums /*[2][BN_SLICE]*/) {
+  const int ncol = 2 * SW, RL = 256 / ncol;
+  const int rl = threadIdx.x / ncol, col = threadIdx.x - rl * ncol;
+  const int k = col >= SW, ch = col - k * SW;
+  if (rl < RL) {
+    float a = 0.f;
+    if (c0 + ch < C) {
+      const float* src = part + (long long)k * C + c0 + ch;
+#pragma unroll 4
+      for (int r = rl; r < nrows; r += RL) a += src[(long long)r * 2 * C];
+    }
+    lds[rl * ncol + col] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < ncol) {
+    float t = 0.f;
+    for (int j = 0; j < RL; ++j) t += lds[j * ncol + threadIdx.x];
+    sums[k * BN_SLICE + ch] = t;
+  }
+  __syncthreads();
+}
+
+// y = relu(gamma*(x-mean)*invstd + beta) [+ y], train mode, with the statistics taken from the folded partial rows
+// of the producing conv; the first pixel group of each slice also writes save and the running statistics.
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_train_kernel(
+    const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy, long long npix, int C,
+    const float* __restrict__ stats, int nrows, float eps, float momentum, float* __restrict__ save,
+    float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, int accumulate) {
+  __shared__ float lds[256];
+  __shared__ float sums[2][BN_SLICE];
+  __shared__ float ab[2][BN_SLICE];
+  SliceWalk w(C);
+  slice_row_sums(stats, nrows, C, w.c0, w.SW, lds, &sums[0][0]);
+  if (threadIdx.x < w.SW && w.c0 + threadIdx.x < C) {
+    const int c = w.c0 + threadIdx.x;
+    const float count = (float)npix;
+    const float mean = sums[0][threadIdx.x] / count;
+    const float var = fmaxf(sums[1][threadIdx.x] / count - mean * mean, 0.f);
+    const float istd = rsqrtf(var + eps);
+    const float a = gamma[c] * istd;
+    ab[0][threadIdx.x] = a;
+    ab[1][threadIdx.x] = beta[c] - mean * a;
+    if (blockIdx.x == 0) {
+      save[c] = mean;
+      save[C + c] = istd;
+      if (running_mean) {
+        float unb = count > 1.f ? var * (count / (count - 1.f)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unb;
+      }
+    }
+  }
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+  __syncthreads();
+  if (!w.active) return;
+  const int c = w.c;
+  float a[8], b[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { a[q] = ab[0][w.cl * 8 + q]; b[q] = ab[1][w.cl * 8 + q]; }
+#pragma unroll 2
+  for (long long p = w.p; p < npix; p += w.step) {
+    float f[8], o[8];
+    unpack8(ld8(x + p * ldx + c), f);
+    if (accumulate) unpack8(ld8(y + p * ldy + c), o);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      float v = f[q] * a[q] + b[q];
+      if (relu) v = fmaxf(v, 0.f);
+      f[q] = accumulate ? v + o[q] : v;
+    }
+    st8(y + p * ldy + c, pack8(f));
+  }
+}
+
+static inline void slice_grid(long long npix, int C, int iters, int cap, dim3& grid) {
+  int ccs = C / 8 < BN_SLICE / 8 ? C / 8 : BN_SLICE / 8;
+  int ppb = EW_THREADS / ccs;
+  grid = dim3(ew_grid(npix, ppb * iters, cap), ceil_div(C, BN_SLICE));
+}
+
+// stats: [nrows][2][C] folded partial sums (ried_conv2d with stats_post = 2 writes min(BN_FOLD_ROWS, tiles) rows).
+extern "C" int ried_bn_fold_rows() { return BN_FOLD_ROWS; }
+extern "C" int ried_bn_apply_train(const void* x, long long ldx, void* y, long long ldy, long long npix, int C,
+                                   const float* stats, int nrows, float eps, float momentum, float* save,
+                                   float* running_mean, float* running_var, long long* num_batches_tracked,
+                                   const float* gamma, const float* beta, int relu, int accumulate,
+                                   hipStream_t stream) {
+  CHECK_VIEW("ried_bn_apply_train", x, ldx, C);
+  CHECK_VIEW("ried_bn_apply_train", y, ldy, C);
+  RIED_CHECK_ARG(stats && save && gamma && beta && npix > 0 && nrows > 0, "ried_bn_apply_train: bad arguments");
+  dim3 grid;
+  slice_grid(npix, C, 2, 8192, grid);
+  hipLaunchKernelGGL(bn_apply_train_kernel, grid, dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy,
+                     npix, C, stats, nrows, eps, momentum, save, running_mean, running_var, num_batches_tracked, gamma,
+                     beta, relu, accumulate);
+  RIED_CHECK_LAUNCH("ried_bn_apply_train");
+  return RIED_OK;
+}
+
+// ---------------------------------------------------------------------------
 // pooling / upsampling (reference: src/rinet.py:235,260,266,330,355,361,428; VGG16 MaxPool2d(2,2))
 // ---------------------------------------------------------------------------
 // mode 0: max 3x3 s2 p1   mode 1: max 2x2 s2 p0   mode 2: avg 3x3 s1 p1 (count_include_pad)

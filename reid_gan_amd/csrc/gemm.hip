@@ -54,6 +54,7 @@ struct GemmEpilogue {
   long long ld_mask;       // fused into the data gradient that produces the tensor); applied after accumulate
   float mask_slope;
   int stats_post;          // stats = column sums of the final values (bias gradient) instead of the raw results
+  int stats_fold;          // > 0: rows are added (float atomics) into row (tile mod stats_fold) of a zeroed buffer
   BnFinalize fin;          // fin.counter != null: the last block to finish turns the stats rows into BN statistics
   const float* sub;        // perceptual-loss tap: d = value - sub[row][m] (the target's features, fp32);
   long long ld_sub;        //   stats rows = column sums of d and d*d, gout[row][m] = gscale * d (the seed of the
@@ -393,7 +394,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
     }
     __syncthreads();
     if (wn == 0 && (lane & 15) == 0) {
-      float* row = E.stats + ((long long)by * ntiles_n + tn) * 2 * P.M;
+      long long ridx = (long long)by * ntiles_n + tn;
+      if (E.stats_fold) ridx %= E.stats_fold;
+      float* row = E.stats + ridx * 2 * P.M;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -401,7 +404,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
           int ml = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
           int m = m0 + ml;
           if (m < P.M) {
-            if (E.fin.counter) {           // read by the last block of this launch: write-through
+            if (E.stats_fold) {            // few rows for the consumer to re-reduce: a short chain of atomics each
+              __hip_atomic_fetch_add(&row[m], ssum[i][q] + red[ml], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_fetch_add(&row[P.M + m], ssq[i][q] + red[BM + ml], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+            } else if (E.fin.counter) {           // read by the last block of this launch: write-through
               ried_publish(&row[m], ssum[i][q] + red[ml]);
               ried_publish(&row[P.M + m], ssq[i][q] + red[BM + ml]);
             } else {
@@ -728,6 +735,7 @@ extern "C" int ried_conv2d_force_tile(int bm, int bn, int nst) {
   g_forced_tile[0] = bm; g_forced_tile[1] = bn; g_forced_tile[2] = nst;
   return RIED_OK;
 }
+extern "C" int ried_bn_fold_rows();
 static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int ksteps) {
   const int* forced = g_forced_tile;
   ConvTile t;
@@ -833,7 +841,8 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   RIED_CHECK_ARG(!y2 || (ldy2 % 4 == 0 && ldy2 >= Cout && ((uintptr_t)y2 % 16) == 0), "ried_conv2d: bad y2 view");
   P.E.out2 = y2; P.E.ldc2 = ldy2;
   RIED_CHECK_ARG(!mask || (ldmask % 4 == 0 && ldmask >= Cout && ((uintptr_t)mask % 8) == 0), "ried_conv2d: bad mask view");
-  P.E.mask = (const bf16_t*)mask; P.E.ld_mask = ldmask; P.E.mask_slope = mask_slope; P.E.stats_post = stats_post;
+  P.E.mask = (const bf16_t*)mask; P.E.ld_mask = ldmask; P.E.mask_slope = mask_slope; P.E.stats_post = stats_post == 1;
+  P.E.stats_fold = stats_post == 2 ? ried_bn_fold_rows() : 0;
   RIED_CHECK_ARG(!sub || (stats && gout && ld_sub % 4 == 0 && ld_gout % 4 == 0 && ((uintptr_t)sub % 16) == 0 &&
                           ((uintptr_t)gout % 8) == 0),
                  "ried_conv2d: bad perceptual-tap arguments");

@@ -119,7 +119,8 @@ class Ctx:
         self._grad_bytes = 0
         self.grad_arena: Optional[torch.Tensor] = None
         self._f32: List[Tuple[torch.Tensor, int, int]] = []
-        self.stats_elems = 0          # fp32 arena zeroed at the start of every forward (BN sums)
+        self.stats_elems = 0          # fp32 arena of per-tile partial rows (BN sums, bias sums): overwritten
+        self.fold_elems = 0           # fp32 arena zeroed at the start of every forward (folded BN sums)
         self.slab_elems = 0
         self.tmp_elems = 0
         self.f32_elems = 0            # shared fp32 scratch (BN backward partial rows, column sums)
@@ -144,9 +145,15 @@ class Ctx:
             self._grad_bytes += (N * H * W * C * 2 + 255) // 256 * 256
         return Act(v, g)
 
-    def stats(self, owner, attr, n):
-        self._stats_req.append((owner, attr, self.stats_elems))
-        self.stats_elems += (n + 3) // 4 * 4
+    def stats(self, owner, attr, n, zeroed=False):
+        """fp32 statistics rows for `owner.attr`; zeroed: from the arena that begin_forward() clears (rows the
+        conv epilogues add into)."""
+        if zeroed:
+            self._stats_req.append((owner, attr, -1 - self.fold_elems))
+            self.fold_elems += (n + 3) // 4 * 4
+        else:
+            self._stats_req.append((owner, attr, self.stats_elems))
+            self.stats_elems += (n + 3) // 4 * 4
         setattr(owner, attr + "_n", n)
 
     def alloc_slab(self, n) -> int:
@@ -182,8 +189,10 @@ class Ctx:
                 g.base, g.ptr = self.grad_arena, base + off
                 seen.add(id(g))
         self.stats_arena = torch.zeros(max(self.stats_elems, 4), dtype=F32, device=dev)
+        self.fold_arena = torch.zeros(max(self.fold_elems, 4), dtype=F32, device=dev)
         for owner, attr, off in self._stats_req:
-            setattr(owner, attr, self.stats_arena[off:off + getattr(owner, attr + "_n")])
+            arena, off = (self.stats_arena, off) if off >= 0 else (self.fold_arena, -1 - off)
+            setattr(owner, attr, arena[off:off + getattr(owner, attr + "_n")])
         self.slab = torch.empty(max(self.slab_elems, 4), dtype=F32, device=dev)
         for j, off in self._wred_slab:
             self.wreds.rows[j][0] = self.slab.data_ptr() + 4 * off
@@ -211,7 +220,9 @@ class Ctx:
         ops.pack_jobs(self.packs)
 
     def begin_forward(self):
-        self.pack_all()          # BN partial-sum rows need no clearing: the conv epilogues overwrite them
+        self.pack_all()          # per-tile partial-sum rows need no clearing: the conv epilogues overwrite them
+        if self.fold_elems and self.training:
+            self.fold_arena.zero_()
 
     def zero_backward(self):
         if not self.chain:       # a chain plan overwrites every gradient buffer before reading it
@@ -236,7 +247,12 @@ class Ctx:
 
 
 N_LANES = 4
-FUSE_MAX_ROWS = int(os.environ.get("RIED_FUSE_MAX_ROWS", "0"))   # measured: the separate finalize launch is faster (0 = never fuse)
+# Train-mode BatchNorm layers of at most BN_FOLD_MAX_ELEMS elements fold their statistics into a few rows with
+# float atomics in the conv epilogue and skip the finalize launch (about 1 % of the step).  The price: the sums
+# depend on the order in which the conv's blocks finish, so two runs differ in the last bits.  BN_FOLD = False
+# (or RIED_DETERMINISTIC=1) keeps every reduction in a fixed order: runs are then bit-reproducible.
+BN_FOLD = not os.environ.get("RIED_DETERMINISTIC")
+BN_FOLD_MAX_ELEMS = 4 << 20
 _side_streams: List["torch.cuda.Stream"] = []
 
 
@@ -409,9 +425,11 @@ class ConvBN:
         self.out, self.accumulate = out, accumulate
         self.raw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
-        self.counters = torch.zeros(2, dtype=torch.int32, device=ctx.device)    # last-block tickets: fwd, bwd
         self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, cin, c.cout, c.kh, c.kw, c.sh, c.sw, deconv)
-        ctx.stats(self, "stats", self.stat_rows * 2 * cout)
+        self.sliced = BN_FOLD and ctx.training and self.raw.npix * cout <= BN_FOLD_MAX_ELEMS
+        if self.sliced:
+            self.stat_rows = min(self.stat_rows, ops.bn_fold_rows())
+        ctx.stats(self, "stats", self.stat_rows * 2 * cout, zeroed=self.sliced)
         self.fold = (torch.empty(ops.bn_finalize_fold_floats(cout), dtype=F32, device=ctx.device)
                      if self.stat_rows > 1024 else None)
         self.draw: Optional[View] = None
@@ -424,12 +442,14 @@ class ConvBN:
 
     def forward(self):
         ctx, c, st = self.ctx, self.core, self.ctx.st
-        if ctx.training and self.stat_rows <= FUSE_MAX_ROWS:
-            # few partial rows: the conv's last block reduces them itself (one dependent launch fewer)
-            ops.conv2d_bn(c.xin.v, c.wp, self.raw, c.kh, c.kw, c.sh, c.sw, c.ph, c.pw, self.stats, self.counters[0:],
-                          self.save, st.b[self.bn + ".running_mean"], st.b[self.bn + ".running_var"],
-                          st.b[self.bn + ".num_batches_tracked"], transposed=c.deconv)
-        elif ctx.training:
+        if self.sliced:
+            c.conv(self.raw, stats=self.stats, stats_post=2)
+            ops.bn_apply_train(self.raw, self.out.v, self.stats, self.stat_rows, self.save,
+                               st.p[self.bn + ".weight"], st.p[self.bn + ".bias"], st.b[self.bn + ".running_mean"],
+                               st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"], relu=True,
+                               accumulate=self.accumulate)
+            return
+        if ctx.training:
             c.conv(self.raw, stats=self.stats)
             ops.bn_finalize(self.stats, self.stat_rows, c.cout, self.raw.npix, self.save,
                             st.b[self.bn + ".running_mean"],
@@ -450,8 +470,7 @@ class ConvBN:
         ctx, c, st = self.ctx, self.core, self.ctx.st
         draw = self.draw
         ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
-                        ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True,
-                        counter=self.counters[1:] if self.raw.npix * c.cout <= FUSE_MAX_ROWS * 8192 else None)
+                        ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True)
         c.wgrad(draw)
 
     def backward_input(self):

@@ -71,7 +71,8 @@ def conv2d(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed
            stats=None, accumulate=False, out_f32=False, y2: Optional[torch.Tensor] = None,
            mask: Optional[View] = None, mask_slope=0.0, stats_post=False):
     """mask: view shaped like y; the stored value is multiplied by (mask > 0 ? 1 : mask_slope) (activation backward
-    fused into a data gradient); stats_post: stats rows receive column sums of the stored values."""
+    fused into a data gradient); stats_post: stats rows receive column sums of the stored values (True / 1), or
+    the raw sums are added into the bn_fold_rows() rows of a zeroed buffer (2: the input of bn_apply_train)."""
     lib.ried_conv2d(x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C, kh, kw, sh, sw, ph, pw,
                     int(transposed), _p(bias), act, _p(stats), int(accumulate), int(out_f32), _p(y2), y.C,
                     None if mask is None else mask.ptr, 0 if mask is None else mask.ld, mask_slope, int(stats_post),
@@ -272,6 +273,17 @@ def bn_backward(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma=
     the layer; with it the reduction's last block finishes the sums (one launch fewer)."""
     lib.ried_bn_backward(dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta),
                          int(relu), _p(scratch), _p(dgamma), _p(dbeta), int(accumulate), _p(counter), _stream())
+
+
+def bn_fold_rows() -> int:
+    return lib.ried_bn_fold_rows()
+
+
+def bn_apply_train(x: View, y: View, stats, nrows, save, gamma, beta, rm=None, rv=None, nbt=None, relu=True,
+                   accumulate=False, eps=1e-5, momentum=0.1):
+    """bn_finalize + bn_apply in one launch, from the folded rows conv2d(..., stats_post=2) accumulated."""
+    lib.ried_bn_apply_train(x.ptr, x.ld, y.ptr, y.ld, x.npix, x.C, _p(stats), nrows, eps, momentum, _p(save), _p(rm),
+                            _p(rv), _p(nbt), _p(gamma), _p(beta), int(relu), int(accumulate), _stream())
 
 
 def conv2d_bn(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, stats, counter, save, rm=None, rv=None,

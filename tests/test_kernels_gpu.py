@@ -344,6 +344,48 @@ def test_bn_forward_backward():
         assert torch.equal(dx2.torch(), dxv.torch()) and torch.equal(dg2, dg) and torch.equal(db2, db)
 
 
+@pytest.mark.parametrize("C,cin,H", [(48, 32, 8), (160, 64, 8), (16, 64, 16), (1024, 64, 4)])
+def test_bn_small_layer_kernels(C, cin, H):
+    """conv with folded (atomic) statistics -> bn_apply_train, against torch and the finalize + apply pair."""
+    N = 8
+    x = (r(N, cin, H, H, seed=30) * 0.7).to(torch.bfloat16).float()
+    w = (r(C, cin, 1, 1, seed=31) * 0.2).to(torch.bfloat16).float()
+    gamma, beta = r(C, seed=32) + 1.0, r(C, seed=33) * 0.3
+    wp = w.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16).to(DEV)
+    raw = ops.new_view(N, H, H, C)
+    nrows = min(ops.bn_fold_rows(), ops.conv2d_stat_rows(N, H, H, cin, C, 1, 1))
+    stats = torch.zeros(nrows * 2 * C, device=DEV)
+    ops.conv2d(to_view(x), wp, raw, 1, 1, 1, 1, 0, 0, stats=stats, stats_post=2)
+    rawf = from_view(raw)                                   # the bf16-rounded conv result, NCHW fp32
+    ref_raw = F.conv2d(x, w)
+    close(rawf, ref_raw, 1e-2, "conv")
+    tot = stats.view(nrows, 2, C).sum(0).cpu()
+    close(tot[0], ref_raw.sum((0, 2, 3)), 1e-2, "folded sum")
+    close(tot[1], (ref_raw * ref_raw).sum((0, 2, 3)), 1e-2, "folded sum of squares")
+    # BatchNorm of the stored (rounded) conv output, statistics from the unrounded accumulators
+    xr = rawf.clone().requires_grad_(True)
+    g2, b2 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(C), torch.ones(C)
+    y = F.relu(F.batch_norm(xr, rm, rv, g2, b2, True, 0.1, 1e-5))
+    save = torch.empty(2, C, device=DEV)
+    rm_d, rv_d = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    yv = ops.new_view(N, H, H, C)
+    ops.bn_apply_train(raw, yv, stats, nrows, save, gamma.to(DEV), beta.to(DEV), rm_d, rv_d, nbt)
+    close(from_view(yv), y.detach(), 2e-2, "y")
+    n = N * H * H                    # the running statistics come from the unrounded accumulators
+    close(rm_d.cpu(), 0.1 * ref_raw.mean((0, 2, 3)), 2e-3, "running_mean")
+    close(rv_d.cpu(), 0.9 + 0.1 * ref_raw.var((0, 2, 3), unbiased=True), 2e-3, "running_var")
+    assert nbt.item() == 1
+    # same as the three-launch kernels on the same statistics
+    save3 = torch.empty(2, C, device=DEV)
+    ops.bn_finalize(stats, nrows, C, N * H * H, save3)
+    close(save.cpu(), save3.cpu(), 1e-5, "save")
+    y3 = ops.new_view(N, H, H, C)
+    ops.bn_apply(raw, y3, save3, gamma.to(DEV), beta.to(DEV))
+    close(from_view(yv), from_view(y3), 1e-2, "y vs three-launch")
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_pool(mode):
     N, C, H = 2, 16, 8
