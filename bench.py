@@ -16,6 +16,7 @@ Extra fields
                 stream in one eager step after the timed region, against the dense bf16 MFMA peak (2.5 PFLOP/s).
   cpu_baseline  the CPU oracle (oracle/ried_oracle.py, a port of the reference arithmetic on stock torch CPU
                 ops, fp32) timed on this host's cores on BASELINE.json configs[0] (batch 4 of 1x64x64).
+  loader        the device patch pipeline (src/loader.py), patches/s with its own HBM roofline (N = 1 only).
   infer         512x512 slice inference + SSIM/PSNR/RMSE (configs[2], batch 32), slices/s (N = 1 only).
 """
 import argparse
@@ -163,6 +164,45 @@ def infer_bench(steps=5, warmup=2, batch=32, size=512):
                                "peak": PEAK_HBM / 1e9, "unit": "GB/s", "frac": bytes_alg / (mms * 1e-3) / PEAK_HBM}}
 
 
+def loader_bench(batch=128, patch=64, patch_n=16, nslices=64, size=512, iters=50, cpu=True):
+    """Patch pipeline (src/loader.py): `batch` patches per launch cut from int16 512x512 slice pairs resident in
+    HBM, fp32 out.  Algorithmic bytes per patch: 2 tensors x P*P x (2 read + 4 written) = 12 B/pixel.  The CPU leg
+    is the oracle's restatement of get_patch + the .float() of train.py:136 on the same slices (one core)."""
+    import numpy as np
+    from reid_gan_amd import loader as L
+    from reid_gan_amd.synth_slices import synth_slices
+    inp, tg = synth_slices(nslices, size, size, seed=5)
+    a, b = torch.from_numpy(inp).cuda(), torch.from_numpy(tg).cuda()
+    nsel = batch // patch_n
+    for _ in range(3):
+        L._crop(a, b, 0, nsel, patch_n, patch, None, 1, 0, True)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        L._crop(a, b, (i * nsel) % (nslices - nsel + 1), nsel, patch_n, patch, None, 1, i * batch, True)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    bytes_alg = batch * patch * patch * 12.0
+    out = {"metric": "training patches/sec cropped + converted on the device", "value": batch / (ms * 1e-3),
+           "unit": "patches/s", "ms_per_batch": ms, "batch": batch, "patch": patch,
+           "roofline": {"bound": "hbm", "achieved": bytes_alg / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9,
+                        "unit": "GB/s", "frac": bytes_alg / (ms * 1e-3) / PEAK_HBM}}
+    if cpu:
+        from oracle import ried_oracle as O
+        np.random.seed(0)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 2.0:
+            for s in range(nsel):
+                px, py = O.get_patch(inp[s], tg[s], patch_n, patch)
+                px.astype(np.float32); py.astype(np.float32)
+            n += batch
+        out["cpu_baseline"] = {"value": n / (time.perf_counter() - t0), "unit": "patches/s", "cores": 1,
+                               "kind": "port", "sample": "numpy get_patch + float conversion, same slices, 2 s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +291,7 @@ def main():
             del ts
             torch.cuda.empty_cache()
             out["infer"] = infer_bench()
+            out["loader"] = loader_bench(cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

@@ -248,6 +248,20 @@ int ried_ssim_fwd(const float* a, const float* b, const float* ref, int nimg, in
 int ried_ssim_bwd(const float* a, const float* ref, const float* gmap, int nimg, int H, int W, float scale,
                   const float* scale_dev, float* da, int accumulate, ried_stream_t stream);
 
+/* ---- training patches ------------------------------------------------------------------------------------------ */
+/* get_patch (src/loader.py:60-73) followed by the .float().view(-1,1,P,P) of src/train.py:136-142, on slices kept
+ * resident in HBM: slices_in / slices_tg are int16 [nslices][H][W] (the .npy files of src/prep.py:24-25); for each
+ * of the nsel slices from first_slice on (the loader does not shuffle, src/loader.py:81), patch_n crops of P x P
+ * at the same position in both.  Patch j = (slice j / patch_n, draw j % patch_n) goes to x_out / y_out
+ * [nsel*patch_n][P][P], fp32 (out_f32) or int16.  offsets: device int [nsel*patch_n][2] = (top, left) per patch,
+ * e.g. drawn on the host with numpy.random.randint(0, H - P) in the reference's order; NULL: positions are
+ * splitmix64(seed, first_draw + j), top from the high and left from the low 32 bits, scaled to [0, H - P) and
+ * [0, W - P).  offsets_out (may be NULL) receives the positions used.  Requires P < H, P < W, P % 4 == 0. */
+int ried_patch_crop(const short* slices_in, const short* slices_tg, int nslices, int H, int W, int first_slice,
+                    int nsel, int patch_n, int P, const int* offsets, unsigned long long seed,
+                    unsigned long long first_draw, void* x_out, void* y_out, int out_f32, int* offsets_out,
+                    ried_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

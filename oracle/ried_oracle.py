@@ -608,3 +608,51 @@ def infer_slice(g_sd: Dict[str, Tensor], x: Tensor, y: Tensor, lo=-160.0, hi=240
         xi, yi, pi = trunc(x[i, 0], lo, hi), trunc(y[i, 0], lo, hi), trunc(pred[i, 0], lo, hi)
         res.append(compute_measure(xi, yi, pi, hi - lo))
     return pred, res, P.sd
+
+
+# ---------------------------------------------------------------------------
+# training patches (src/loader.py)
+# ---------------------------------------------------------------------------
+def get_patch(full_input_img, full_target_img, patch_n: int, patch_size: int):
+    """src/loader.py:60-73 on numpy arrays: patch_n crops at positions drawn from numpy's global generator,
+    top then left (loader.py:67-68), the same position in both images.  Pinned by tests/golden/loader.npz
+    (made by calling the reference's get_patch / get_loader on seeded synthetic slices)."""
+    import numpy as np
+    assert full_input_img.shape == full_target_img.shape
+    h, w = full_input_img.shape
+    xs, ys = [], []
+    for _ in range(patch_n):
+        top = np.random.randint(0, h - patch_size)
+        left = np.random.randint(0, w - patch_size)
+        xs.append(full_input_img[top:top + patch_size, left:left + patch_size])
+        ys.append(full_target_img[top:top + patch_size, left:left + patch_size])
+    return np.array(xs), np.array(ys)
+
+
+def loader_batches(inputs, targets, patch_n: int, patch_size: int, batch_size: int):
+    """What iterating get_loader(...) yields (src/loader.py:41-57,76-82: in order, no shuffle, default collate):
+    (x, y) arrays of shape (batch, patch_n, P, P), the last batch possibly smaller."""
+    import numpy as np
+    for first in range(0, len(inputs), batch_size):
+        xs, ys = [], []
+        for i in range(first, min(first + batch_size, len(inputs))):
+            a, b = get_patch(inputs[i], targets[i], patch_n, patch_size)
+            xs.append(a); ys.append(b)
+        yield np.stack(xs), np.stack(ys)
+
+
+def device_patch_offsets(seed: int, first_draw: int, n: int, h: int, w: int, patch_size: int):
+    """The crop positions the device generator of ried_patch_crop uses when no offsets are supplied: splitmix64 of
+    (seed, draw), top from the high and left from the low 32 bits, each scaled to [0, h-P) / [0, w-P) by a
+    multiply-shift.  (The product's own definition, restated with Python integers; no reference counterpart.)"""
+    import numpy as np
+    M = (1 << 64) - 1
+    out = np.empty((n, 2), dtype=np.int32)
+    for j in range(n):
+        z = (seed + (first_draw + j + 1) * 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        z ^= z >> 31
+        out[j, 0] = ((z >> 32) * (h - patch_size)) >> 32
+        out[j, 1] = ((z & 0xffffffff) * (w - patch_size)) >> 32
+    return out

@@ -18,6 +18,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "ried_gan.h")
 _CTYPES = {
     "int": ctypes.c_int,
     "long long": ctypes.c_longlong,
+    "unsigned long long": ctypes.c_ulonglong,
     "float": ctypes.c_float,
     "ried_stream_t": ctypes.c_void_p,
 }
