@@ -216,7 +216,8 @@ class TrainStep:
 
     def _snapshot(self):
         s = {"g": self.gs.flat.clone(), "d": self.ds.flat.clone(),
-             "gb": {k: v.clone() for k, v in self.gs.b.items()}, "db": {k: v.clone() for k, v in self.ds.b.items()}}
+             "gb": {k: v.clone() for k, v in self.gs.b.items()}, "db": {k: v.clone() for k, v in self.ds.b.items()},
+             "adam": [(st.adam_m.clone(), st.adam_v.clone(), st.adam_step.clone()) for st in (self.gs, self.ds)]}
         return s
 
     def _restore(self, s):
@@ -225,8 +226,8 @@ class TrainStep:
             self.gs.b[k].copy_(v)
         for k, v in s["db"].items():
             self.ds.b[k].copy_(v)
-        for st in (self.gs, self.ds):
-            st.adam_m.zero_(); st.adam_v.zero_(); st.adam_step.zero_()
+        for st, (m, v, n) in zip((self.gs, self.ds), s["adam"]):      # e.g. moments restored from a checkpoint
+            st.adam_m.copy_(m); st.adam_v.copy_(v); st.adam_step.copy_(n)
 
     def losses(self) -> Dict[str, float]:
         """Host read of the last step's scalars (synchronises)."""
