@@ -656,3 +656,20 @@ def device_patch_offsets(seed: int, first_draw: int, n: int, h: int, w: int, pat
         out[j, 0] = ((z >> 32) * (h - patch_size)) >> 32
         out[j, 1] = ((z & 0xffffffff) * (w - patch_size)) >> 32
     return out
+
+
+# ---------------------------------------------------------------------------
+# MPL (src/loss.py:89-110)
+# ---------------------------------------------------------------------------
+def mpl_loss(vgg: Dict[str, Tensor], target: Tensor, prediction: Tensor) -> Tensor:
+    """src/loss.py:96-110: per tap (modules 3, 8, 15, 22, 29 of VGG16 features on cat([img]*3) of the RAW images,
+    loss.py:36 applies no normalisation) the channel L2 norm of the feature difference / (H*W), mean over batch and
+    positions, summed over taps.  Parity unpinned: src/loss.py is not importable here (torchvision is absent), so
+    this follows the text of the reference."""
+    ft = vgg_taps(vgg, torch.cat([target, target, target], 1))
+    fp = vgg_taps(vgg, torch.cat([prediction, prediction, prediction], 1))
+    total = torch.zeros((), dtype=torch.float32)
+    for a, b in zip(ft, fp):
+        _, _, h, w = a.shape
+        total = total + (torch.linalg.norm(a - b, dim=1, ord=2) / float(h * w)).mean()
+    return total

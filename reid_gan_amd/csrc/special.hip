@@ -677,6 +677,58 @@ extern "C" int ried_mse_tap(const void* a, const void* b, long long n, float los
   return RIED_OK;
 }
 
+// MPL tap (src/loss.py:101-109): loss[0] += loss_scale * sum over pixels of ||a[p][:] - b[p][:]||_2 ;
+// g[p][c] = grad_scale * (a - b)[p][c] / ||a[p] - b[p]||  (0 where the norm is 0).  a, b: fp32 [npix][C].
+// C/8 lanes (a power of two, at most 64) share a pixel; the groups of a wave work on different pixels.
+__global__ __launch_bounds__(SP_THREADS) void l2norm_tap_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                                long long npix, int C, float loss_scale,
+                                                                float* __restrict__ loss, bf16_t* __restrict__ g,
+                                                                float grad_scale) {
+  __shared__ float sh[4];
+  const int L = C >> 3, gl = threadIdx.x & (L - 1), pg = threadIdx.x / L, PPB = SP_THREADS / L;
+  float acc = 0.f;
+  for (long long base = (long long)blockIdx.x * PPB; base < npix; base += (long long)gridDim.x * PPB) {
+    const long long p = base + pg;
+    const bool valid = p < npix;
+    float d[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) d[q] = 0.f;
+    if (valid) {
+      const long long o = p * C + gl * 8;
+      f32x4 a0 = *reinterpret_cast<const f32x4*>(a + o), a1 = *reinterpret_cast<const f32x4*>(a + o + 4);
+      f32x4 b0 = *reinterpret_cast<const f32x4*>(b + o), b1 = *reinterpret_cast<const f32x4*>(b + o + 4);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { d[q] = a0[q] - b0[q]; d[4 + q] = a1[q] - b1[q]; }
+    }
+    float ss = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) ss += d[q] * d[q];
+    for (int o = L >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float nrm = sqrtf(ss);
+    if (valid && gl == 0) acc += nrm;
+    if (valid && g) {
+      const float s = nrm > 0.f ? grad_scale / nrm : 0.f;
+      *reinterpret_cast<u32x4*>(g + p * C + gl * 8) = u32x4{pack2bf(d[0] * s, d[1] * s), pack2bf(d[2] * s, d[3] * s),
+                                                            pack2bf(d[4] * s, d[5] * s), pack2bf(d[6] * s, d[7] * s)};
+    }
+  }
+  float t = block_sum_256(acc, sh);
+  if (threadIdx.x == 0 && loss) atomicAdd(loss, t * loss_scale);
+}
+
+extern "C" int ried_l2norm_tap(const void* a, const void* b, long long npix, int C, float loss_scale, float* loss,
+                               void* g, float grad_scale, hipStream_t stream) {
+  RIED_CHECK_ARG(a && b && npix > 0, "ried_l2norm_tap: bad arguments");
+  RIED_CHECK_ARG(C >= 8 && C <= 512 && (C & (C - 1)) == 0, "ried_l2norm_tap: C must be a power of two in [8, 512]");
+  RIED_CHECK_ARG(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)g % 16) == 0,
+                 "ried_l2norm_tap: alignment");
+  const int ppb = SP_THREADS / (C / 8);
+  hipLaunchKernelGGL(l2norm_tap_kernel, dim3(ew_grid(npix, ppb * 2, 1024)), dim3(SP_THREADS), 0, stream,
+                     (const float*)a, (const float*)b, npix, C, loss_scale, loss, (bf16_t*)g, grad_scale);
+  RIED_CHECK_LAUNCH("ried_l2norm_tap");
+  return RIED_OK;
+}
+
 // ---------------------------------------------------------------------------
 // loss scalars (src/loss.py:141-142, 154-155, 194).  sc is a small fp32 device array:
 //  in : sc[0] = mean(pos)  sc[1] = mean(neg)

@@ -1101,9 +1101,13 @@ class Vgg:
     identical input channels of torch.cat([x,x,x]) (src/loss.py:181-182) are folded into the first layer's
     weights.  backward() propagates only through the prediction half and only to the data."""
 
-    def __init__(self, weights: Dict[str, torch.Tensor], B: int, H: int, W: int, grads=True, device="cuda"):
+    def __init__(self, weights: Dict[str, torch.Tensor], B: int, H: int, W: int, grads=True, device="cuda",
+                 normalize=True):
+        """normalize: apply normalize_ (src/loss.py:20-22, (x+1024)/4096) on load, as CompoundLoss does
+        (src/loss.py:179-180); MPL feeds the raw images (src/loss.py:36,101-102)."""
         self.ctx = ctx = Ctx(None, device, grads, training=False)
         self.B, self.H, self.W = B, H, W
+        self.in_scale, self.in_shift = (1.0 / 4096.0, 0.25) if normalize else (1.0, 0.0)
         N = 2 * B
         dev = device
         self.w0 = weights["0.weight"].to(dev, F32).sum(1).reshape(64, 9).contiguous()     # fold 3 -> 1 channel
@@ -1151,7 +1155,7 @@ class Vgg:
         the target half can run early, beside other work, and the prediction half once it exists."""
         n1 = 2 * self.B if n1 is None else n1
         a0 = self.a0.images(n0, n1)
-        ops.conv_c1_fwd(imgs[n0:n1], self.w0, a0.v, 1, bias=self.b0, in_scale=1.0 / 4096.0, in_shift=0.25, act=1)
+        ops.conv_c1_fwd(imgs[n0:n1], self.w0, a0.v, 1, bias=self.b0, in_scale=self.in_scale, in_shift=self.in_shift, act=1)
         for l in self.layers:
             if l[0] == "pool":
                 p = l[1]
@@ -1168,7 +1172,7 @@ class Vgg:
         loss_from_rows() and backward()."""
         B = self.B
         a0 = self.a0.images(0, B)
-        ops.conv_c1_fwd(imgs[0:B], self.w0, a0.v, 1, bias=self.b0, in_scale=1.0 / 4096.0, in_shift=0.25, act=1)
+        ops.conv_c1_fwd(imgs[0:B], self.w0, a0.v, 1, bias=self.b0, in_scale=self.in_scale, in_shift=self.in_shift, act=1)
         for l in self.layers:
             if l[0] == "pool":
                 p = l[1]
@@ -1202,6 +1206,17 @@ class Vgg:
             ops.mse_tap(a, b, n, 1.0 / (n * len(self.taps)), loss, g, 2.0 * weight / (n * len(self.taps)),
                         accumulate=False)
 
+    def mpl_loss_and_seed(self, loss: torch.Tensor, weight: float = 1.0):
+        """MPL (src/loss.py:96-110): loss[0] += sum over taps of mean over (n, h, w) of ||tap(target) - tap(pred)||_2
+        over channels / (h*w); seeds each tap's gradient (prediction half) with weight * d/d tap."""
+        B = self.B
+        for t, t32 in self.taps:
+            v = t.v
+            npix = B * v.H * v.W
+            a, b = t32.data_ptr(), t32.data_ptr() + 4 * npix * v.C
+            s = 1.0 / (npix * v.H * v.W)
+            ops.l2norm_tap(a, b, npix, v.C, s, loss, t.g.images(0, B).ptr if self.ctx.grads else None, weight * s)
+
     def backward(self, dimg: torch.Tensor):
         """dimg: fp32 (B,1,H,W), += d loss / d prediction image."""
         B = self.B
@@ -1222,4 +1237,4 @@ class Vgg:
                     core.dgrad(out.images(0, B).g, xi.g, accumulate=in_is_tap, mask=xi.v, mask_slope=0.0)
                 else:
                     core.dgrad(out.images(0, B).g, xi.g, accumulate=False)
-        ops.conv_c1_dgrad(self.a0.images(0, B).g, self.w0, dimg, scale=1.0 / 4096.0, accumulate=True)
+        ops.conv_c1_dgrad(self.a0.images(0, B).g, self.w0, dimg, scale=self.in_scale, accumulate=True)

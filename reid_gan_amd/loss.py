@@ -23,8 +23,8 @@ from . import ops
 from .engine import Vgg
 from .synth import synth_vgg
 
-__all__ = ["normalize_", "gaussian", "create_window", "compute_SSIM", "Vgg16FeatureExtractor", "SSIM", "DLoss",
-           "GLoss", "CompoundLoss", "to_cuda", "load_vgg16_state"]
+__all__ = ["normalize_", "gaussian", "create_window", "get_feature_layer_vgg16", "compute_SSIM",
+           "Vgg16FeatureExtractor", "MPL", "SSIM", "DLoss", "GLoss", "CompoundLoss", "to_cuda", "load_vgg16_state"]
 
 F32 = torch.float32
 cuda_is_present = torch.cuda.is_available()
@@ -215,6 +215,74 @@ class Vgg16FeatureExtractor(nn.Module):
         # the plan applies normalize_ on load; undo it for already-normalised input
         V.forward((x.to(F32) * 4096.0 - 1024.0).contiguous())
         return [t32.permute(0, 3, 1, 2).contiguous() for _, t32 in V.taps]
+
+
+_TAP_OF_LAYER = {3: 0, 8: 1, 15: 2, 22: 3, 29: 4}
+
+
+def get_feature_layer_vgg16(image, layer, model):
+    """Output of module `layer` of VGG16 features on cat([image]*3, 1) (reference: src/loss.py:35-40).  image:
+    (B, 1, H, W), fed as it is (the reference applies no normalisation here); layer: one of the post-ReLU taps 3,
+    8, 15, 22, 29; model: an MPL or Vgg16FeatureExtractor of this package (the owner of the VGG16 weights).
+    Returns NCHW fp32, no gradient."""
+    if layer not in _TAP_OF_LAYER:
+        raise NotImplementedError("the HIP plan taps modules 3, 8, 15, 22, 29")
+    ops.require_gpu()
+    B, _, H, W = image.shape
+    key = ("raw", B, H, W)
+    V = model._plans.get(key)
+    if V is None:
+        if B % 2:
+            raise NotImplementedError("get_feature_layer_vgg16: batch must be even")
+        V = model._plans[key] = Vgg(model.weights, B // 2, H, W, grads=False, device=image.device, normalize=False)
+    V.forward(image.detach().to(F32).contiguous())
+    return V.taps[_TAP_OF_LAYER[layer]][1].permute(0, 3, 1, 2).contiguous()
+
+
+class _MplFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mod, target, prediction):
+        B, _, H, W = prediction.shape
+        V = mod._plan(B, H, W, prediction.device)
+        p = prediction.detach().to(F32).contiguous()
+        t = target.detach().to(F32).contiguous()
+        loss = torch.zeros(1, dtype=F32, device=p.device)
+        dpred = torch.zeros_like(p)
+        V.forward(torch.cat([p, t], 0))
+        V.ctx.zero_backward()
+        V.mpl_loss_and_seed(loss)
+        if prediction.requires_grad:
+            V.backward(dpred)
+        ctx.save_for_backward(dpred)
+        ctx.pshape = prediction.shape
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, go):
+        (dpred,) = ctx.saved_tensors
+        return None, None, (dpred * go.to(F32)).reshape(ctx.pshape)
+
+
+class MPL(nn.Module):
+    """The Multi Perceptual Loss (reference: src/loss.py:89-110): for each of the taps 3, 8, 15, 22, 29 of VGG16
+    on the raw (not normalised) images, the channel-wise L2 norm of the feature difference divided by the tap's
+    H*W, averaged over batch and positions; summed over the taps.  forward(target, prediction); the gradient
+    flows to `prediction` (the reference's training script never asks for the target's)."""
+
+    def __init__(self, vgg_state=None):
+        super().__init__()
+        self.weights = load_vgg16_state(vgg_state)
+        self._plans = {}
+
+    def _plan(self, B, H, W, device):
+        key = (B, H, W)
+        if key not in self._plans:
+            self._plans[key] = Vgg(self.weights, B, H, W, grads=True, device=device, normalize=False)
+        return self._plans[key]
+
+    def forward(self, target, prediction):
+        ops.require_gpu()
+        return _MplFn.apply(self, target, prediction)
 
 
 class _CompoundFn(torch.autograd.Function):

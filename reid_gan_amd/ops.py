@@ -404,6 +404,11 @@ def sn_backward(dWsn, Wm, u, v, sigma, R, K, dW, scratch1, accumulate=False):
                          _stream())
 
 
+def l2norm_tap(a_ptr, b_ptr, npix, C, loss_scale, loss, g_ptr, grad_scale):
+    """loss[0] += loss_scale * sum over pixels of the channel L2 norm of (a - b); g = grad_scale * d/da."""
+    lib.ried_l2norm_tap(a_ptr, b_ptr, npix, C, loss_scale, _p(loss), g_ptr, grad_scale, _stream())
+
+
 def mse_tap(a_ptr, b_ptr, n, loss_scale, loss, g_ptr, grad_scale, accumulate=False):
     lib.ried_mse_tap(a_ptr, b_ptr, n, loss_scale, _p(loss), g_ptr, grad_scale, int(accumulate), _stream())
 

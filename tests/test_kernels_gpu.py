@@ -386,6 +386,23 @@ def test_bn_small_layer_kernels(C, cin, H):
     close(from_view(yv), from_view(y3), 1e-2, "y vs three-launch")
 
 
+@pytest.mark.parametrize("C,npix", [(64, 1000), (512, 37), (8, 300)])
+def test_l2norm_tap(C, npix):
+    a = r(npix, C, seed=40).requires_grad_(True)
+    b = r(npix, C, seed=41)
+    with torch.no_grad():
+        a[5] = b[5]                                  # a zero difference: norm 0, gradient 0 (not NaN)
+    ref = torch.linalg.norm(a - b, dim=1).sum() * 0.25
+    ref.backward()
+    ad, bd = a.detach().to(DEV), b.to(DEV)
+    loss_d = torch.zeros(1, device=DEV)
+    g = torch.full((npix, C), float("nan"), dtype=torch.bfloat16, device=DEV)
+    ops.l2norm_tap(ad.data_ptr(), bd.data_ptr(), npix, C, 0.25, loss_d, g.data_ptr(), 0.25)
+    close(loss_d.cpu(), ref.detach().reshape(1), 1e-5, "loss")
+    close(g.float().cpu(), a.grad, 5e-3, "gradient")
+    assert g[5].abs().max().item() == 0.0
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_pool(mode):
     N, C, H = 2, 16, 8

@@ -158,6 +158,37 @@ def test_compound_loss_against_oracle():
     assert [t.shape[1] for t in taps] == [64, 128, 256, 512, 512]
 
 
+def test_mpl_against_oracle():
+    """MPL (src/loss.py:89-110) and get_feature_layer_vgg16 against the oracle's restatement (bf16 storage emulated);
+    parity with the reference itself is unpinned: loss.py needs torchvision, which is not installed."""
+    vgg = synth_vgg()
+    B, H = 2, 32
+    pred, y = synth_batch(B, H, seed=43)
+    pr = pred.clone().requires_grad_(True)
+    O.set_bf16_emulation(True)
+    try:
+        ref = O.mpl_loss(vgg, y, pr)
+        ref.backward()
+        tap8 = O.vgg_taps(vgg, torch.cat([torch.cat([pred, y], 0)] * 3, 1))[1]
+    finally:
+        O.set_bf16_emulation(False)
+    crit = loss.MPL(vgg_state=vgg)
+    p = pred.cuda().requires_grad_(True)
+    got = crit(y.cuda(), p)
+    got.backward()
+    assert abs(got.item() - ref.item()) < 1e-2 * abs(ref.item()), (got.item(), ref.item())
+    a, b = p.grad.cpu().double().flatten(), pr.grad.double().flatten()
+    # the gradient is a field of unit directions d/|d|: rounding noise in small feature differences turns them
+    # more than it changes the loss (measured cosine 0.986 at this size)
+    assert (torch.dot(a, b) / (a.norm() * b.norm())).item() > 0.97
+    assert abs(a.norm().item() / b.norm().item() - 1.0) < 0.05
+    f = loss.get_feature_layer_vgg16(torch.cat([pred, y], 0).cuda(), 8, crit).cpu()
+    assert f.shape == tap8.shape == (2 * B, 128, H // 2, H // 2)
+    assert (f - tap8).abs().mean().item() <= 1e-2 * tap8.abs().mean().item()
+    with pytest.raises(NotImplementedError):
+        loss.get_feature_layer_vgg16(pred.cuda(), 5, crit)
+
+
 def test_reference_training_loop_shape():
     """The body of the reference's train.py:153-177, verbatim in structure, on the drop-in modules with
     torch.optim.Adam: it runs (the reference's own modules raise here on torch >= 1.5) and the first
