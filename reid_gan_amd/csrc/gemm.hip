@@ -55,6 +55,8 @@ struct GemmEpilogue {
   float mask_slope;
   int stats_post;          // stats = column sums of the final values (bias gradient) instead of the raw results
   int stats_fold;          // > 0: rows are added (float atomics) into row (tile mod stats_fold) of a zeroed buffer
+  int stats_zero;          // f > 1: the caller sized the buffer for f times as many rows; block t also zeroes
+                           //        rows ntiles + t*(f-1) .. + f-2, so that every row is defined
   BnFinalize fin;          // fin.counter != null: the last block to finish turns the stats rows into BN statistics
   const float* sub;        // perceptual-loss tap: d = value - sub[row][m] (the target's features, fp32);
   long long ld_sub;        //   stats rows = column sums of d and d*d, gout[row][m] = gscale * d (the seed of the
@@ -278,13 +280,33 @@ __device__ __forceinline__ bf16x8_t read_frag(const bf16_t* lds, int rowbase, in
 // ---------------------------------------------------------------------------
 // epilogue shared by the GEMM kernels: acc[i][j] is the 16x16 tile (i along m, j along n) of wave (wm, wn)
 // ---------------------------------------------------------------------------
-template <int BM, int BN, bool WGRAD>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[BM / 32][BN / 32], int m0, int n0,
-                                              int tn, int pa, int pb, long long batch, int ntiles_n, int by, int bz,
-                                              unsigned nblocks, void* smem) {
-  constexpr int TM = BM / 32, TN = BN / 32;
+// Row n of the GEMM (counted from the block's first) -> row of the output tensor; false: outside the problem.
+struct LinearRowMap {
+  const GemmParams& P;
+  int n0, pa, pb;
+  __device__ __forceinline__ bool operator()(int nl, long long& orow) const {
+    const GemmEpilogue& E = P.E;
+    const int n = n0 + nl;
+    orow = n;
+    if (E.phase_mode) {          // logical (img, hq, wq) of this phase -> physical pixel
+      int hw = E.Hq * E.Wq;
+      int rem, wq;
+      int img = fast_div(n, hw, 1.0f / (float)hw, rem);
+      int hq = fast_div(rem, E.Wq, 1.0f / (float)E.Wq, wq);
+      orow = (long long)img * E.HoWo_full + (long long)(hq * E.sh + pa) * E.Wo_full + (wq * E.sw + pb);
+    }
+    return n < P.N;
+  }
+};
+
+// Waves are arranged 2 (along m) x WN (along n); wave (wm, wn) owns rows [wm*BM/2, +BM/2) x [wn*BN/WN, +BN/WN).
+template <int BM, int BN, bool WGRAD, int WN = 2, class RowMap = LinearRowMap>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[BM / 32][BN / (16 * WN)], int m0,
+                                              const RowMap& rowmap, int tn, long long batch, int ntiles_n, int by,
+                                              int bz, unsigned nblocks, void* smem) {
+  constexpr int TM = BM / 32, TN = BN / (16 * WN);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const GemmEpilogue& E = P.E;
   const float gam = E.gamma ? E.gamma[0] : 0.f;
   char* outb = (char*)E.out;
@@ -298,16 +320,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    int n = n0 + wn * (BN / 2) + j * 16 + (lane & 15);
-    bool nok = n < P.N;
-    long long orow = n;
-    if (E.phase_mode) {          // logical (img, hq, wq) of this phase -> physical pixel
-      int hw = E.Hq * E.Wq;
-      int rem, wq;
-      int img = fast_div(n, hw, 1.0f / (float)hw, rem);
-      int hq = fast_div(rem, E.Wq, 1.0f / (float)E.Wq, wq);
-      orow = (long long)img * E.HoWo_full + (long long)(hq * E.sh + pa) * E.Wo_full + (wq * E.sw + pb);
-    }
+    long long orow;
+    const bool nok = rowmap(wn * (BN / WN) + j * 16 + (lane & 15), orow);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       int m = m0 + wm * (BM / 2) + i * 16 + (lane >> 4) * 4;
@@ -372,7 +386,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
     // Per-block partial sums, one row of [2][M] per (phase, pixel tile): same-address float atomics serialise at
     // about 0.1 us each on this part, which at thousands of blocks would dwarf the convolution itself.
     // Rows n that are out of range were loaded as zeros, so they add nothing.
-    float* red = reinterpret_cast<float*>(smem);          // [2][BM]; the k loop ended with a barrier
+    float* red = reinterpret_cast<float*>(smem);          // [WN-1][2][BM]; the k loop ended with a barrier
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -383,13 +397,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
         ssum[i][q] = a; ssq[i][q] = b;
       }
     }
-    if (wn == 1 && (lane & 15) == 0) {
+    if (wn > 0 && (lane & 15) == 0) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           int ml = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
-          red[ml] = ssum[i][q]; red[BM + ml] = ssq[i][q];
+          red[(wn - 1) * 2 * BM + ml] = ssum[i][q]; red[(wn - 1) * 2 * BM + BM + ml] = ssq[i][q];
         }
     }
     __syncthreads();
@@ -404,16 +418,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
           int ml = wm * (BM / 2) + i * 16 + (lane >> 4) * 4 + q;
           int m = m0 + ml;
           if (m < P.M) {
+            float s0 = ssum[i][q], s1 = ssq[i][q];
+#pragma unroll
+            for (int w = 0; w < WN - 1; ++w) { s0 += red[w * 2 * BM + ml]; s1 += red[w * 2 * BM + BM + ml]; }
             if (E.stats_fold) {            // few rows for the consumer to re-reduce: a short chain of atomics each
-              __hip_atomic_fetch_add(&row[m], ssum[i][q] + red[ml], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_fetch_add(&row[P.M + m], ssq[i][q] + red[BM + ml], __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_fetch_add(&row[m], s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_fetch_add(&row[P.M + m], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (E.fin.counter) {           // read by the last block of this launch: write-through
-              ried_publish(&row[m], ssum[i][q] + red[ml]);
-              ried_publish(&row[P.M + m], ssq[i][q] + red[BM + ml]);
+              ried_publish(&row[m], s0);
+              ried_publish(&row[P.M + m], s1);
             } else {
-              row[m] = ssum[i][q] + red[ml];
-              row[P.M + m] = ssq[i][q] + red[BM + ml];
+              row[m] = s0;
+              row[P.M + m] = s1;
+              for (int e = 0; e < E.stats_zero - 1; ++e) {
+                float* z = E.stats + ((long long)ntiles_n + (long long)tn * (E.stats_zero - 1) + e) * 2 * P.M;
+                z[m] = 0.f; z[P.M + m] = 0.f;
+              }
             }
           }
         }
@@ -544,7 +564,7 @@ __device__ __forceinline__ void igemm_body(const GemmParams& P, int bx, int by, 
     __syncthreads();
   }
 
-  gemm_epilogue<BM, BN, WGRAD>(P, acc, m0, n0, tn, pa, pb, batch, ntiles_n, by, bz, nblocks, smem);
+  gemm_epilogue<BM, BN, WGRAD>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, batch, ntiles_n, by, bz, nblocks, smem);
 }
 
 template <int BM, int BN, int AKIND, int BKIND>
@@ -587,16 +607,19 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned byt
                                            (int)byte_off, 0, 0, 0);
 }
 
-template <int BM, int BN, int NST>
-__global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
-  constexpr int TM = BM / 32, TN = BN / 32;
-  constexpr int NLA = BM / 32, NLB = BN / 32;         // 16-byte DMA loads per lane per stage
+// NT threads: 256 (2 x 2 waves) or 512 (2 x 4 waves: twice the pixels per block for the same weight traffic).
+template <int BM, int BN, int NST, int NT = 256>
+__global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
+  constexpr int WN = NT / 128;                        // waves along the pixel axis
+  constexpr int RPP = NT / 8;                         // rows per DMA pass (8 lanes = one 128-byte row)
+  constexpr int TM = BM / 32, TN = BN / (16 * WN);
+  constexpr int NLA = BM / RPP, NLB = BN / RPP;       // 16-byte DMA loads per lane per stage
   constexpr int STAGE = (BM + BN) * 128;              // bytes per stage: A image then B image
   __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   // XCD-aware order: consecutive hardware block ids go round-robin over the 8 XCDs; give each XCD a
   // contiguous run of logical tiles so that the blocks sharing a pixel tile hit one L2.
@@ -628,7 +651,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
   unsigned wrow[NLA];                                   // byte offset of the row in the packed weights
 #pragma unroll
   for (int i = 0; i < NLA; ++i) {
-    int m = m0 + i * 32 + rowp;
+    int m = m0 + i * RPP + rowp;
     wrow[i] = m < P.M ? (unsigned)m * (unsigned)P.A.ld * 2u : GLDS_OOB;      // stays out of range after + wk: wk < 2^28
   }
   int gy[NLB], gx[NLB], pix[NLB];
@@ -636,7 +659,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
   const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)X.Wo;
 #pragma unroll
   for (int i = 0; i < NLB; ++i) {
-    int n = n0 + i * 32 + rowp;
+    int n = n0 + i * RPP + rowp;
     int rem, ox;
     int img = fast_div(n, hw, inv_hw, rem);
     int oy = fast_div(rem, X.Wo, inv_wo, ox);
@@ -648,7 +671,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
   int c, ti, tj;
   { int tap = kq / CPT; c = kq - tap * CPT; ti = tap / tj_n; tj = tap - ti * tj_n; }
 
-  char* const lds_wave = smem + wave * 1024;            // + i * 4096 per row pass, + BM * 128 for B
+  char* const lds_wave = smem + wave * 1024;            // + i * NT * 16 per row pass, + BM * 128 for B
   const unsigned ldx2 = (unsigned)X.ld * 2u;
 
   // Offsets are 16-byte aligned, so OR-ing GLDS_OOB into one leaves it out of range whatever its value: validity
@@ -660,14 +683,14 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
     asm volatile("" : "+v"(inval));
     const unsigned wk = (unsigned)(((r0 + ti * rstep) * X.kw + (s0 + tj * sstep)) * P.K + c * 8) * 2u;
 #pragma unroll
-    for (int i = 0; i < NLA; ++i) glds16(rsA, (wrow[i] + wk) | inval, dst + i * 4096);
+    for (int i = 0; i < NLA; ++i) glds16(rsA, (wrow[i] + wk) | inval, dst + i * (NT * 16));
     const int dpx = dir * (ti * X.W + tj);
     const unsigned cb = (unsigned)c * 16u;
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
       int hi = gy[i] + dir * ti, wi = gx[i] + dir * tj;
       unsigned bad = ((unsigned)hi < (unsigned)X.H && (unsigned)wi < (unsigned)X.W) ? 0u : GLDS_OOB;
-      glds16(rsB, ((unsigned)(pix[i] + dpx) * ldx2 + cb) | bad | inval, dst + BM * 128 + i * 4096);
+      glds16(rsB, ((unsigned)(pix[i] + dpx) * ldx2 + cb) | bad | inval, dst + BM * 128 + i * (NT * 16));
     }
     c += 8;
     while (c >= CPT) {
@@ -687,7 +710,7 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
   bf16x8_t fa[2][TM], fb[2][TN];
   auto load_frags = [&](int buf, int ks) {
     const char* sa = smem + buf * STAGE + wm * (BM / 2) * 128 + frow;
-    const char* sb = smem + buf * STAGE + BM * 128 + wn * (BN / 2) * 128 + frow;
+    const char* sb = smem + buf * STAGE + BM * 128 + wn * (BN / WN) * 128 + frow;
     const int sw = ks ? sw1 : sw0;
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + sw);
@@ -721,8 +744,165 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may outlive the block or race the epilogue
   __builtin_amdgcn_s_barrier();
-  gemm_epilogue<BM, BN, false>(P, acc, m0, n0, tn, pa, pb, 0, gridDim.x / P.tiles_m, blockIdx.y, 0,
-                               gridDim.x * gridDim.y, smem);
+  gemm_epilogue<BM, BN, false, WN>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, 0, gridDim.x / P.tiles_m, blockIdx.y,
+                                   0, gridDim.x * gridDim.y, smem);
+}
+
+// ---------------------------------------------------------------------------
+// 3x3, stride 1, pad 1 convolution (forward, or the data gradient of one: flip = 1), third form.  The kernel
+// above fetches the input pixels of a tile once per tap: nine times the bytes through L2, which is what bounds
+// layers with 64-256 input channels on large maps.  Here a block owns 256 output pixels as TS x TS tiles at one
+// position of 256 / TS^2 consecutive images (one 16x16 tile, or 8x8 tiles of four images) and loads the input
+// tiles - the outputs' halo included, (TS+2)^2 pixels each - into LDS once per 64-channel slab; the nine taps
+// read their operand fragments from that image at shifted rows.  Only the weights (BM x 64 per tap) stream
+// through a three-stage ring.  Per 64-channel slab a 128 x 16x16 block moves 9 * 128 * 128 + 324 * 128 bytes for
+// 2 * 128 * 256 * 576 flops: 3.1x the arithmetic intensity of the 128x128 form.
+//
+// 512 threads = 2 x 4 waves, each wave BM/2 rows x 64 pixels (4 tile rows, or one 8x8 tile).  All loads are
+// LDS-DMA with out-of-range offsets for padding (zeros).  The taps of a slab are unrolled, so every wait is a
+// counted s_waitcnt with a compile-time count: the weights of step k+2 and one part of the next slab's input
+// tile are issued in step k and stay in flight across two barriers.
+// Requires Cin % 64 == 0, H % TS == 0, W % TS == 0 (host-checked).
+// ---------------------------------------------------------------------------
+template <int BM, int TS>
+__global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
+  constexpr int BN = 256, WN = 4;
+  constexpr int IMG = BN / (TS * TS);                      // images per block: 1 or 4
+  constexpr int TWP = TS + 2, HRI = TWP * TWP, HR = IMG * HRI;   // input pixels per tile, per block: 324 / 400
+  constexpr int NLB = (HR * 8 + 511) / 512;                // 16-byte DMA loads per lane per slab: 6 / 7
+  constexpr int BBUF = NLB * 512 * 16;
+  static_assert(TS == 16 || TS == 8, "tile side");
+  constexpr int NLA = BM * 8 / 512;                        // per weight stage: 2 (BM 128) or 1 (BM 64)
+  constexpr int ABUF = BM * 128;
+  constexpr int TM = BM / 32, TN = 4;
+  constexpr unsigned A_OOB = 0xFFFF0000u, B_OOB = 0xFFFFF000u;   // + the largest k offset: still out of range, no wrap
+  __shared__ __attribute__((aligned(1024))) char smem[3 * ABUF + 2 * BBUF];
+  char* const sA = smem;
+  char* const sB = smem + 3 * ABUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const GemmOperand& X = P.B;
+  const int tm = bid % P.tiles_m, tn = bid / P.tiles_m;
+  const int m0 = tm * BM;
+  const int tX = X.W / TS, tY = X.H / TS;
+  const int img0 = (tn / (tX * tY)) * IMG, trem = tn % (tX * tY);
+  const int ty0 = (trem / tX) * TS, tx0 = (trem % tX) * TS;
+  const int flip = X.transposed;
+  const int nsl = P.K >> 6;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A.p, 0, P.A_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B.p, 0, P.B_bytes, 0x00020000);
+  unsigned aoff[NLA], boff[NLB];
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) {
+    const int ci = i * 512 + tid, m = ci >> 3, q = (ci & 7) ^ (m & 7);
+    aoff[i] = m0 + m < P.M ? (unsigned)(m0 + m) * (unsigned)P.A.ld * 2u + (unsigned)q * 16u : A_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < NLB; ++i) {
+    const int ci = i * 512 + tid, hr = ci >> 3, q = (ci & 7) ^ (hr & 7);
+    const int il = hr / HRI, hp = hr - il * HRI;
+    const int hy = hp / TWP, hx = hp - hy * TWP;
+    const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
+    const bool ok = hr < HR && img0 + il < X.nimg && (unsigned)iy < (unsigned)X.H && (unsigned)ix < (unsigned)X.W;
+    boff[i] = ok ? (unsigned)(((img0 + il) * X.H + iy) * X.W + ix) * (unsigned)X.ld * 2u + (unsigned)q * 16u : B_OOB;
+  }
+  char* const dA = sA + wave * 1024;
+  char* const dB = sB + wave * 1024;
+  // weights of step (slab, tap) -> ring stage; steps past the end fetch zeros into a stage nobody reads any more
+  auto issueA = [&](int slab, int tap, int stage) {
+    unsigned dead = slab < nsl ? 0u : A_OOB;
+    asm volatile("" : "+v"(dead));
+    const unsigned wk = (unsigned)(tap * P.K + slab * 64) * 2u;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) glds16(rsA, (aoff[i] + wk) | dead, dA + stage * ABUF + i * 8192);
+  };
+  auto issueB = [&](int slab, int part) {
+    unsigned dead = slab < nsl ? 0u : B_OOB;
+    asm volatile("" : "+v"(dead));
+    glds16(rsB, (boff[part] + (unsigned)slab * 128u) | dead, dB + (slab & 1) * BBUF + part * 8192);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = (lane & 15) * 128;
+  const int kq0 = lane >> 4, kq1 = 4 + (lane >> 4);
+  const int sw0 = (kq0 ^ (lane & 7)) << 4, sw1 = (kq1 ^ (lane & 7)) << 4;
+  int hr0[TN];                       // LDS row of this lane's pixel (n = wn*64 + j*16 + lane%16) before the tap shift
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nl = wn * 64 + j * 16 + (lane & 15);
+    const int il = nl / (TS * TS), p = nl % (TS * TS);
+    hr0[j] = il * HRI + (p / TS) * TWP + (p % TS);
+  }
+  bf16x8_t fa[2][TM], fb[2][TN];
+  auto load_frags = [&](int stage, int bbuf, int toff, int ks) {
+    const char* sa = sA + stage * ABUF + wm * (BM / 2) * 128 + frow;
+    const char* sb = sB + bbuf * BBUF;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + (ks ? sw1 : sw0));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int hr = hr0[j] + toff;
+      fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + hr * 128 + (((ks ? kq1 : kq0) ^ (hr & 7)) << 4));
+    }
+  };
+  auto mfmas = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+  };
+
+#pragma unroll
+  for (int part = 0; part < NLB; ++part) issueB(0, part);
+  issueA(0, 0, 0);
+  issueA(0, 1, 1);
+  for (int slab = 0; slab < nsl; ++slab) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      // loads issued after the weights of this step: the input-tile part of step-2 (if any), the weights of
+      // step+1, the input-tile part of step-1 (if any); everything older has landed once only those remain
+      const int n_after = ((tap + 7) % 9 < NLB ? 1 : 0) + NLA + ((tap + 8) % 9 < NLB ? 1 : 0);
+      if (n_after == NLA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA) : "memory");
+      else if (n_after == NLA + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + 2) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const int r = tap / 3, c = tap - r * 3;
+      const int toff = flip ? (2 - r) * TWP + (2 - c) : r * TWP + c;
+      load_frags(tap % 3, slab & 1, toff, 0);
+      if (tap < 7) issueA(slab, tap + 2, (tap + 2) % 3);
+      else issueA(slab + 1, tap - 7, (tap + 2) % 3);
+      if (tap < NLB) issueB(slab + 1, tap);
+      load_frags(tap % 3, slab & 1, toff, 1);
+      mfmas(0);
+      mfmas(1);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  struct TileRowMap {
+    long long base; int W, HW, nimg_left;
+    __device__ __forceinline__ bool operator()(int nl, long long& orow) const {
+      const int il = nl / (TS * TS), p = nl % (TS * TS);
+      orow = base + (long long)il * HW + (long long)(p / TS) * W + (p % TS);
+      return il < nimg_left;
+    }
+  };
+  const TileRowMap rm{((long long)img0 * X.H + ty0) * X.W + tx0, X.W, X.H * X.W, X.nimg - img0};
+  gemm_epilogue<BM, BN, false, WN>(P, acc, m0, rm, tn, 0, gridDim.x / P.tiles_m, 0, 0, gridDim.x, smem);
 }
 
 // Tile of the convolution kernel for a problem: Cout x pixels per phase.  Small problems take 64-pixel tiles
@@ -730,7 +910,8 @@ __global__ __launch_bounds__(256) void conv_glds_kernel(const GemmParams P) {
 struct ConvTile { int bm, bn, nst; };
 static int g_forced_tile[3] = {0, 0, 0};
 // Tuning hook: force the tile (bm, bn, nst) of every later ried_conv2d call in this process; bm = 0 restores the
-// built-in choice.  Layers with Cout <= 64 keep bm = 64.
+// built-in choice; bm = -1 keeps the built-in tiles of the general kernel.  Any non-zero bm turns the halo-tile
+// kernel off.  Layers with Cout <= 64 keep bm = 64.
 extern "C" int ried_conv2d_force_tile(int bm, int bn, int nst) {
   g_forced_tile[0] = bm; g_forced_tile[1] = bn; g_forced_tile[2] = nst;
   return RIED_OK;
@@ -756,6 +937,13 @@ static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int kstep
   if (t.bm == 128 && b64 <= 256) {
     t.bm = 64; t.bn = 64;
     if (ksteps >= 24) t.nst = 4;
+  }
+  // Large maps of heavy layers (measured on the discriminator's strided and 1x1 layers and the 4x4 deconvs):
+  // 256-pixel tiles on 8 waves halve the weight traffic per pixel; 64 output channels per block unless the
+  // layer has at least 256.
+  if (npix >= 32768 && (double)npix * ksteps * 64.0 * Cout * phases >= 2.5e9) {
+    t.bn = 256; t.nst = 2;
+    t.bm = Cout >= 256 ? 128 : 64;
   }
   if (forced[0] > 0) {
     t.bm = forced[0]; t.bn = forced[1]; t.nst = forced[2];
@@ -853,6 +1041,25 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                  "ried_conv2d: operand larger than 4 GiB");
   P.A_bytes = (unsigned)a_bytes; P.B_bytes = (unsigned)b_bytes;
   ConvTile t = choose_conv_tile(Cout, npix, phases, conv_ksteps(Cin, kh, kw, sh, sw, transposed));
+  // 3x3 stride-1 layers on maps of whole 16x16 tiles: the halo-tile kernel (the input tile serves all nine taps)
+  if (g_forced_tile[0] == 0 && !fin && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 &&
+      Cin % 64 == 0 && H % 8 == 0 && W % 8 == 0 && a_bytes < 0xFFFF0000ll - 16384 && b_bytes < 0xFFFFF000ll - 1024 &&
+      (nimg % 4 == 0 || (H % 16 == 0 && W % 16 == 0))) {
+    // 16x16 tiles where the map allows; 8x8 tiles of four images otherwise (64 output channels per block there:
+    // the small maps have few pixel tiles, and LDS holds two 400-pixel input tiles beside the weight ring)
+    const int ts = (H % 16 == 0 && W % 16 == 0) ? 16 : 8;
+    const int bm = (Cout <= 64 || ts == 8) ? 64 : 128;
+    P.tiles_m = ceil_div(Cout, bm);
+    const int ntiles = ceil_div(nimg, 256 / (ts * ts)) * (H / ts) * (W / ts);
+    // the caller sized the statistics buffer for the other kernel's rows (npix / t.bn): the spare ones are zeroed
+    if (stats && !P.E.stats_fold) P.E.stats_zero = 256 / t.bn;
+    const dim3 hgrid(P.tiles_m * ntiles);
+    if (ts == 8) hipLaunchKernelGGL((conv_halo_kernel<64, 8>), hgrid, dim3(512), 0, stream, P);
+    else if (bm == 64) hipLaunchKernelGGL((conv_halo_kernel<64, 16>), hgrid, dim3(512), 0, stream, P);
+    else hipLaunchKernelGGL((conv_halo_kernel<128, 16>), hgrid, dim3(512), 0, stream, P);
+    RIED_CHECK_LAUNCH("ried_conv2d");
+    return RIED_OK;
+  }
   P.tiles_m = ceil_div(Cout, t.bm);
   dim3 grid(P.tiles_m * ceil_div(npix, t.bn), phases, 1);
   if (fin) {
@@ -861,10 +1068,14 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   }
 #define RIED_CONV_CASE(BM_, BN_, NST_)                                                                  \
   if (t.bm == BM_ && t.bn == BN_ && t.nst == NST_) {                                                    \
-    hipLaunchKernelGGL((conv_glds_kernel<BM_, BN_, NST_>), grid, dim3(256), 0, stream, P);              \
+    if (BN_ == 256)                                                                                     \
+      hipLaunchKernelGGL((conv_glds_kernel<BM_, BN_, NST_, 512>), grid, dim3(512), 0, stream, P);       \
+    else                                                                                                \
+      hipLaunchKernelGGL((conv_glds_kernel<BM_, (BN_ == 256 ? 128 : BN_), NST_>), grid, dim3(256), 0, stream, P); \
     launched = true;                                                                                    \
   }
   bool launched = false;
+  RIED_CONV_CASE(128, 256, 2) RIED_CONV_CASE(128, 256, 3) RIED_CONV_CASE(64, 256, 2) RIED_CONV_CASE(64, 256, 3)
   RIED_CONV_CASE(128, 128, 2) RIED_CONV_CASE(128, 128, 3) RIED_CONV_CASE(128, 64, 2) RIED_CONV_CASE(128, 64, 3)
   RIED_CONV_CASE(128, 64, 4) RIED_CONV_CASE(64, 128, 2) RIED_CONV_CASE(64, 128, 3) RIED_CONV_CASE(64, 128, 4)
   RIED_CONV_CASE(64, 64, 2) RIED_CONV_CASE(64, 64, 3) RIED_CONV_CASE(64, 64, 4)

@@ -11,6 +11,7 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 from reid_gan_amd import ops
+from reid_gan_amd._lib import lib
 from reid_gan_amd.ops import View
 
 DEV = "cuda"
@@ -98,6 +99,74 @@ def test_conv2d_forward_stats(cin, cout, k, s, p, H):
     m, v = ref.mean((0, 2, 3)), ref.var((0, 2, 3), unbiased=False) * n / (n - 1)
     close(rm.cpu(), 0.19 * m, 3e-2, "running mean after two steps")
     close(rv.cpu(), 0.81 + 0.19 * v, 3e-3, "running var after two steps")
+
+
+HALO_CASES = [
+    # cin, cout, N, H, W, transposed
+    (64, 64, 2, 16, 32, False),
+    (128, 192, 1, 32, 16, False),       # a second, partial tile of output channels
+    (256, 72, 3, 16, 16, False),
+    (64, 128, 2, 32, 32, True),         # the data gradient of a 3x3 s1 p1 conv
+    (192, 64, 1, 16, 48, True),
+    (512, 128, 4, 8, 8, False),         # 8x8 tiles of four images per block
+    (128, 72, 8, 8, 24, True),
+    (64, 64, 12, 24, 8, False),
+]
+
+
+@pytest.mark.parametrize("cin,cout,N,H,W,tr", HALO_CASES)
+def test_conv2d_halo_tile_kernel(cin, cout, N, H, W, tr):
+    """3x3 s1 p1 layers on maps of whole 16x16 tiles take the halo-tile kernel: against torch, and every epilogue
+    feature against the general kernel (ried_conv2d_force_tile(-1) turns the halo kernel off)."""
+    x = r(N, cin, H, W, seed=50)
+    b = r(cout, seed=52)
+    if tr:
+        w = r(cin, cout, 3, 3, seed=51, scale=(cin * 9) ** -0.5)
+        ref = F.conv_transpose2d(x, w, None, 1, 1)
+        wp = pack(w.permute(1, 0, 2, 3))
+    else:
+        w = r(cout, cin, 3, 3, seed=51, scale=(cin * 9) ** -0.5)
+        ref = F.conv2d(x, w, None, 1, 1)
+        wp = pack(w)
+    xv = to_view(x)
+    rows = ops.conv2d_stat_rows(N, H, W, cin, cout, 3, 3, 1, 1, tr)
+    out = {}
+    for name, force in (("halo", 0), ("general", -1)):
+        lib.ried_conv2d_force_tile(force, 0, 0)
+        try:
+            yv = ops.new_view(N, H, W, cout)
+            stats = torch.full((rows, 2, cout), float("nan"), device=DEV)     # every row must be defined afterwards
+            ops.conv2d(xv, wp, yv, 3, 3, 1, 1, 1, 1, transposed=tr, stats=stats)
+            # bias + ReLU + fp32 copy into a channel slice, then accumulate + mask + post-mask column sums
+            big = ops.new_view(N, H, W, cout + 16, zero=True)
+            y2 = torch.zeros(N, H, W, cout, device=DEV)
+            ops.conv2d(xv, wp, big.slice(8, 8 + cout), 3, 3, 1, 1, 1, 1, transposed=tr, bias=b.to(DEV), act=1, y2=y2)
+            acc = to_view(ref * 0.5)
+            mask = to_view(r(N, cout, H, W, seed=53))
+            st2 = torch.full((rows, 2, cout), float("nan"), device=DEV)
+            ops.conv2d(xv, wp, acc, 3, 3, 1, 1, 1, 1, transposed=tr, accumulate=True, mask=mask, mask_slope=0.2,
+                       stats=st2, stats_post=True)
+            fold = torch.zeros(ops.bn_fold_rows(), 2, cout, device=DEV)
+            ops.conv2d(xv, wp, ops.new_view(N, H, W, cout), 3, 3, 1, 1, 1, 1, transposed=tr, stats=fold, stats_post=2)
+            out[name] = (from_view(yv), stats.sum(0).cpu(), from_view(big), y2.cpu(), from_view(acc), st2.sum(0).cpu(),
+                         fold.sum(0).cpu())
+        finally:
+            lib.ried_conv2d_force_tile(0, 0, 0)
+    y, st, bg, y2, ac, s2, fo = out["halo"]
+    close(y, ref, what="y")
+    close(st[0], ref.sum((0, 2, 3)), 3e-2, "sum")
+    close(st[1], (ref * ref).sum((0, 2, 3)), 3e-3, "sumsq")
+    want = F.relu(ref + b.view(1, -1, 1, 1))
+    close(bg[:, 8:8 + cout], want, what="bias + relu into a slice")
+    assert bg[:, :8].abs().max() == 0 and bg[:, 8 + cout:].abs().max() == 0
+    close(y2.permute(0, 3, 1, 2), want, 1e-3, "fp32 copy")
+    m = r(N, cout, H, W, seed=53).to(torch.bfloat16).float()
+    wanted = (ref + (ref * 0.5).to(torch.bfloat16).float()) * torch.where(m > 0, 1.0, 0.2)
+    close(ac, wanted, what="accumulate + mask")
+    close(s2[0], wanted.sum((0, 2, 3)), 3e-2, "post-mask column sums")
+    close(fo[1], (ref * ref).sum((0, 2, 3)), 3e-3, "folded sumsq")
+    for a, g, what in zip(out["halo"], out["general"], ("y", "stats", "slice", "y2", "acc", "stats2", "fold")):
+        close(a, g, 4e-3, what + " vs general kernel")
 
 
 def test_bn_finalize_folds_many_rows():
