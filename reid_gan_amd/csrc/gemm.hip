@@ -762,10 +762,13 @@ __global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
 // LDS-DMA with out-of-range offsets for padding (zeros).  The taps of a slab are unrolled, so every wait is a
 // counted s_waitcnt with a compile-time count: the weights of step k+2 and one part of the next slab's input
 // tile are issued in step k and stay in flight across two barriers.
+// NBB = 1: layers with exactly 64 input channels have one slab and need no second input-tile buffer; with 64
+// output channels per block two blocks then fit a CU (73 KB of LDS, 128 registers), so that one block's prologue
+// and epilogue - most of its life when K is nine steps - overlap the other's main loop.
 // Requires Cin % 64 == 0, H % TS == 0, W % TS == 0 (host-checked).
 // ---------------------------------------------------------------------------
-template <int BM, int TS>
-__global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
+template <int BM, int TS, int NBB = 2>
+__global__ __launch_bounds__(512, NBB == 1 ? 4 : 2) void conv_halo_kernel(const GemmParams P) {
   constexpr int BN = 256, WN = 4;
   constexpr int IMG = BN / (TS * TS);                      // images per block: 1 or 4
   constexpr int TWP = TS + 2, HRI = TWP * TWP, HR = IMG * HRI;   // input pixels per tile, per block: 324 / 400
@@ -776,7 +779,8 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   constexpr int ABUF = BM * 128;
   constexpr int TM = BM / 32, TN = 4;
   constexpr unsigned A_OOB = 0xFFFF0000u, B_OOB = 0xFFFFF000u;   // + the largest k offset: still out of range, no wrap
-  __shared__ __attribute__((aligned(1024))) char smem[3 * ABUF + 2 * BBUF];
+  constexpr int PARTS = NBB == 2 ? NLB : 0;                // input-tile loads issued inside the loop per slab
+  __shared__ __attribute__((aligned(1024))) char smem[3 * ABUF + NBB * BBUF];
   char* const sA = smem;
   char* const sB = smem + 3 * ABUF;
 
@@ -827,7 +831,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
   auto issueB = [&](int slab, int part) {
     unsigned dead = slab < nsl ? 0u : B_OOB;
     asm volatile("" : "+v"(dead));
-    glds16(rsB, (boff[part] + (unsigned)slab * 128u) | dead, dB + (slab & 1) * BBUF + part * 8192);
+    glds16(rsB, (boff[part] + (unsigned)slab * 128u) | dead, dB + (slab & (NBB - 1)) * BBUF + part * 8192);
   };
 
   f32x4 acc[TM][TN];
@@ -875,18 +879,18 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const GemmParams P) {
     for (int tap = 0; tap < 9; ++tap) {
       // loads issued after the weights of this step: the input-tile part of step-2 (if any), the weights of
       // step+1, the input-tile part of step-1 (if any); everything older has landed once only those remain
-      const int n_after = ((tap + 7) % 9 < NLB ? 1 : 0) + NLA + ((tap + 8) % 9 < NLB ? 1 : 0);
+      const int n_after = ((tap + 7) % 9 < PARTS ? 1 : 0) + NLA + ((tap + 8) % 9 < PARTS ? 1 : 0);
       if (n_after == NLA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA) : "memory");
       else if (n_after == NLA + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + 1) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + 2) : "memory");
       __builtin_amdgcn_s_barrier();
       const int r = tap / 3, c = tap - r * 3;
       const int toff = flip ? (2 - r) * TWP + (2 - c) : r * TWP + c;
-      load_frags(tap % 3, slab & 1, toff, 0);
+      load_frags(tap % 3, slab & (NBB - 1), toff, 0);
       if (tap < 7) issueA(slab, tap + 2, (tap + 2) % 3);
       else issueA(slab + 1, tap - 7, (tap + 2) % 3);
-      if (tap < NLB) issueB(slab + 1, tap);
-      load_frags(tap % 3, slab & 1, toff, 1);
+      if (tap < PARTS) issueB(slab + 1, tap);
+      load_frags(tap % 3, slab & (NBB - 1), toff, 1);
       mfmas(0);
       mfmas(1);
     }
@@ -1048,13 +1052,14 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     // 16x16 tiles where the map allows; 8x8 tiles of four images otherwise (64 output channels per block there:
     // the small maps have few pixel tiles, and LDS holds two 400-pixel input tiles beside the weight ring)
     const int ts = (H % 16 == 0 && W % 16 == 0) ? 16 : 8;
-    const int bm = (Cout <= 64 || ts == 8) ? 64 : 128;
+    const int bm = (Cout <= 64 || ts == 8 || Cin == 64) ? 64 : 128;
     P.tiles_m = ceil_div(Cout, bm);
     const int ntiles = ceil_div(nimg, 256 / (ts * ts)) * (H / ts) * (W / ts);
     // the caller sized the statistics buffer for the other kernel's rows (npix / t.bn): the spare ones are zeroed
     if (stats && !P.E.stats_fold) P.E.stats_zero = 256 / t.bn;
     const dim3 hgrid(P.tiles_m * ntiles);
     if (ts == 8) hipLaunchKernelGGL((conv_halo_kernel<64, 8>), hgrid, dim3(512), 0, stream, P);
+    else if (bm == 64 && Cin == 64) hipLaunchKernelGGL((conv_halo_kernel<64, 16, 1>), hgrid, dim3(512), 0, stream, P);
     else if (bm == 64) hipLaunchKernelGGL((conv_halo_kernel<64, 16>), hgrid, dim3(512), 0, stream, P);
     else hipLaunchKernelGGL((conv_halo_kernel<128, 16>), hgrid, dim3(512), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
