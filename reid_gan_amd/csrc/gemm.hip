@@ -55,8 +55,8 @@ struct GemmEpilogue {
   float mask_slope;
   int stats_post;          // stats = column sums of the final values (bias gradient) instead of the raw results
   int stats_fold;          // > 0: rows are added (float atomics) into row (tile mod stats_fold) of a zeroed buffer
-  int stats_zero;          // f > 1: the caller sized the buffer for f times as many rows; block t also zeroes
-                           //        rows ntiles + t*(f-1) .. + f-2, so that every row is defined
+  int stats_zero;          // f > 1: the caller sized the buffer for f times as many rows as the stats_rows this
+  int stats_rows;          //        launch writes; the writer of row t also zeroes rows stats_rows + t*(f-1) .. + f-2
   BnFinalize fin;          // fin.counter != null: the last block to finish turns the stats rows into BN statistics
   const float* sub;        // perceptual-loss tap: d = value - sub[row][m] (the target's features, fp32);
   long long ld_sub;        //   stats rows = column sums of d and d*d, gout[row][m] = gscale * d (the seed of the
@@ -64,6 +64,8 @@ struct GemmEpilogue {
   long long ld_gout;
   float gscale;
   int phase_mode, Wo_full, HoWo_full, Hq, Wq, sh, sw;   // logical row -> physical pixel
+  int staged;              // bf16 output with every view 16-byte aligned: the convolution kernels may take the
+                           // LDS-staged epilogue (full-line loads and stores)
 };
 
 struct GemmParams {
@@ -431,7 +433,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
               row[m] = s0;
               row[P.M + m] = s1;
               for (int e = 0; e < E.stats_zero - 1; ++e) {
-                float* z = E.stats + ((long long)ntiles_n + (long long)tn * (E.stats_zero - 1) + e) * 2 * P.M;
+                float* z = E.stats + ((long long)E.stats_rows + ((long long)by * ntiles_n + tn) * (E.stats_zero - 1) + e) *
+                                         2 * P.M;
                 z[m] = 0.f; z[P.M + m] = 0.f;
               }
             }
@@ -442,6 +445,158 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
       float* scratch = reinterpret_cast<float*>(smem) + 1024;
       if (ried_last_block(E.fin.counter, nblocks, reinterpret_cast<int*>(smem) + 768))
         bn_finalize_rows(E.stats, P.M, E.fin, scratch);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// The same epilogue for the convolution kernels, staged through LDS.  In the MFMA layout a lane owns 4 channels of
+// one pixel, so the direct form above reads and writes 8-byte pieces: a wave instruction touches 16 pixel rows
+// with 32 bytes each.  For layers whose output (plus mask, accumulate or tap traffic) is large - measured: more
+// than half the time of the stride-2 data gradients - that is what bounds the kernel.  Here the accumulators go
+// to LDS as an fp32 [pixel][channel] tile, half of the block's channels at a time, and every thread then owns a
+// 16-byte chunk (8 channels) of a pixel row: 8 or 4 consecutive lanes read and write one contiguous 128 / 64
+// bytes of each tensor.  Statistics are summed per thread (its chunk column is fixed), across the lanes of a wave
+// by shuffles and across waves through LDS.
+// Handles bf16 outputs with bias, activation, fp32 copy, perceptual tap, accumulate, mask and statistics rows
+// (plain, folded, zero-padded); not the BatchNorm hand-off, the attention residual or fp32 outputs.
+// ---------------------------------------------------------------------------
+// SMEM: bytes of LDS the kernel owns; if the whole tile fits it is staged at once, else in two halves.
+template <int BM, int BN, int WN, int SMEM, class RowMap>
+__device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 (&acc)[BM / 32][BN / (16 * WN)],
+                                                     int m0, const RowMap& rowmap, int tn, int ntiles_n, int by,
+                                                     void* smem) {
+  constexpr int NT = 128 * WN, NW = 2 * WN, TM = BM / 32, TN = BN / (16 * WN);
+  constexpr int HALVES = (BN * (BM + 4) * 4 + NW * 2 * BM * 4 <= SMEM) ? 1 : 2;
+  static_assert(BN * (BM / HALVES + 4) * 4 + NW * 2 * (BM / HALVES) * 4 <= SMEM, "staging area");
+  constexpr int HM = BM / HALVES;             // channels per pass: all, or the rows of waves wm = 0, then wm = 1
+  constexpr int LDT = HM + 4;                 // floats per staged pixel row (16-byte pad: conflict-free both ways)
+  constexpr int CPR = HM / 8;                 // 16-byte output chunks per pixel row
+  constexpr int RPP = NT / CPR;               // pixel rows per pass of the block
+  static_assert(BN % RPP == 0, "tile shape");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const GemmEpilogue& E = P.E;
+  float* T = reinterpret_cast<float*>(smem);
+  float* red = T + BN * LDT;                  // [NW][2][HM] wave totals of the statistics
+  const int c = tid % CPR, r0 = tid / CPR;
+  bf16_t* outb = (bf16_t*)E.out + (long long)by * E.tap_stride;
+  const bool pre = E.stats && !E.stats_post && !E.sub;
+#pragma unroll
+  for (int h = 0; h < HALVES; ++h) {
+    if (h) __syncthreads();                   // the first half has been read
+    if (HALVES == 1 || wm == h) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = wn * (BN / WN) + j * 16 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          f32x4 v = acc[i][j];
+          v[0] *= E.alpha; v[1] *= E.alpha; v[2] *= E.alpha; v[3] *= E.alpha;
+          *reinterpret_cast<f32x4*>(T + n * LDT + (HALVES == 1 ? wm * (BM / 2) : 0) + i * 16 + (lane >> 4) * 4) = v;
+        }
+      }
+    }
+    __syncthreads();
+    const int m = m0 + h * HM + c * 8;
+    const bool mok = m < P.M;
+    float bias8[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) bias8[q] = (E.bias && mok) ? E.bias[m + q] : 0.f;
+    float s0[8], s1[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
+#pragma unroll 2
+    for (int n = r0; n < BN; n += RPP) {
+      float v[8];
+      {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(T + n * LDT + c * 8);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(T + n * LDT + c * 8 + 4);
+        v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+      }
+      if (pre) {                              // rows outside the problem were computed from zeros
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s0[q] += v[q]; s1[q] += v[q] * v[q]; }
+      }
+      long long orow;
+      if (!(rowmap(n, orow) && mok)) continue;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] += bias8[q];
+      if (E.act == 1) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], 0.f);
+      } else if (E.act == 2) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = v[q] > 0.f ? v[q] : 0.2f * v[q];
+      }
+      if (E.out2) {
+        float* o2 = E.out2 + orow * E.ldc2 + m;
+        *reinterpret_cast<f32x4*>(o2) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(o2 + 4) = f32x4{v[4], v[5], v[6], v[7]};
+      }
+      if (E.sub) {
+        const float* tp = E.sub + orow * E.ld_sub + m;
+        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+        float d[8] = {v[0] - t0[0], v[1] - t0[1], v[2] - t0[2], v[3] - t0[3],
+                      v[4] - t1[0], v[5] - t1[1], v[6] - t1[2], v[7] - t1[3]};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s0[q] += d[q]; s1[q] += d[q] * d[q]; d[q] *= E.gscale; }
+        *reinterpret_cast<u32x4*>(E.gout + orow * E.ld_gout + m) =
+            u32x4{pack2bf(d[0], d[1]), pack2bf(d[2], d[3]), pack2bf(d[4], d[5]), pack2bf(d[6], d[7])};
+      }
+      bf16_t* op = outb + orow * E.ldc + m;
+      if (E.accumulate) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(op);
+        v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
+        v[4] += bflo(o[2]); v[5] += bfhi(o[2]); v[6] += bflo(o[3]); v[7] += bfhi(o[3]);
+      }
+      if (E.mask) {
+        const u32x4 mk = *reinterpret_cast<const u32x4*>(E.mask + orow * E.ld_mask + m);
+        const float sl = E.mask_slope;
+        v[0] *= bflo(mk[0]) > 0.f ? 1.f : sl; v[1] *= bfhi(mk[0]) > 0.f ? 1.f : sl;
+        v[2] *= bflo(mk[1]) > 0.f ? 1.f : sl; v[3] *= bfhi(mk[1]) > 0.f ? 1.f : sl;
+        v[4] *= bflo(mk[2]) > 0.f ? 1.f : sl; v[5] *= bfhi(mk[2]) > 0.f ? 1.f : sl;
+        v[6] *= bflo(mk[3]) > 0.f ? 1.f : sl; v[7] *= bfhi(mk[3]) > 0.f ? 1.f : sl;
+      }
+      if (E.stats && E.stats_post) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s0[q] += v[q]; s1[q] += v[q] * v[q]; }
+      }
+      *reinterpret_cast<u32x4*>(op) =
+          u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+    }
+    if (E.stats) {
+      // lanes with equal lane % CPR hold the same chunk column: butterfly over the others, then one row per wave
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+#pragma unroll
+        for (int o = CPR; o < 64; o <<= 1) { s0[q] += __shfl_xor(s0[q], o, 64); s1[q] += __shfl_xor(s1[q], o, 64); }
+      }
+      if (lane < CPR) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          red[(wave * 2 + 0) * HM + lane * 8 + q] = s0[q];
+          red[(wave * 2 + 1) * HM + lane * 8 + q] = s1[q];
+        }
+      }
+      __syncthreads();
+      if (tid < 2 * HM) {
+        const int k = tid / HM, ch = tid - k * HM, mm = m0 + h * HM + ch;
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += red[(w * 2 + k) * HM + ch];
+        if (mm < P.M) {
+          long long ridx = (long long)by * ntiles_n + tn;
+          if (E.stats_fold) {
+            __hip_atomic_fetch_add(E.stats + (ridx % E.stats_fold) * 2 * P.M + (long long)k * P.M + mm, t,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          } else {
+            E.stats[ridx * 2 * P.M + (long long)k * P.M + mm] = t;
+            for (int e = 0; e < E.stats_zero - 1; ++e)
+              E.stats[((long long)E.stats_rows + ridx * (E.stats_zero - 1) + e) * 2 * P.M + (long long)k * P.M + mm] = 0.f;
+          }
+        }
+      }
     }
   }
 }
@@ -744,8 +899,12 @@ __global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may outlive the block or race the epilogue
   __builtin_amdgcn_s_barrier();
-  gemm_epilogue<BM, BN, false, WN>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, 0, gridDim.x / P.tiles_m, blockIdx.y,
-                                   0, gridDim.x * gridDim.y, smem);
+  if (P.E.staged)
+    gemm_epilogue_staged<BM, BN, WN, NST * STAGE>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, gridDim.x / P.tiles_m,
+                                                  blockIdx.y, smem);
+  else
+    gemm_epilogue<BM, BN, false, WN>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, 0, gridDim.x / P.tiles_m,
+                                     blockIdx.y, 0, gridDim.x * gridDim.y, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -906,7 +1065,169 @@ __global__ __launch_bounds__(512, NBB == 1 ? 4 : 2) void conv_halo_kernel(const 
     }
   };
   const TileRowMap rm{((long long)img0 * X.H + ty0) * X.W + tx0, X.W, X.H * X.W, X.nimg - img0};
-  gemm_epilogue<BM, BN, false, WN>(P, acc, m0, rm, tn, 0, gridDim.x / P.tiles_m, 0, 0, gridDim.x, smem);
+  gemm_epilogue_staged<BM, BN, WN, 3 * ABUF + NBB * BBUF>(P, acc, m0, rm, tn, gridDim.x / P.tiles_m, 0, smem);
+}
+
+// ---------------------------------------------------------------------------
+// Data gradient of a 3x3, stride 2, pad 1 convolution (= transposed convolution onto a 2H x 2W map), halo-tile
+// form.  The general kernel runs each of the four output phases (row parity, column parity) as its own short
+// GEMM - 1, 2, 2 and 4 taps - and fetches the input once per tap.  Here a block owns TS x TS input positions
+// (of one image, or 8x8 of four) and ALL FOUR phases of the 2TS x 2TS output pixels they produce: the
+// (TS+1)^2 input tile is loaded into LDS once per 64-channel slab and the nine (phase, tap) products of a slab
+// run as the nine steps of the same pipeline as conv_halo_kernel, each step adding into its phase's accumulators
+// (4 x 64 x 256 fp32 per block: 64 output channels per block).  One block thus has a K loop of 9 * Cin/64 steps
+// and four epilogues instead of four blocks with loops of 1-4 steps each.
+// Requires Cin % 64 == 0, H % TS == 0, W % TS == 0 (host-checked).
+// ---------------------------------------------------------------------------
+struct S2tStep { int phase, wtap, shift_i, shift_j; };
+// phase = 2*(row parity) + column parity; weight tap r*3+s with (parity + 1 - r) even; input shift (parity+1-r)/2
+__device__ constexpr S2tStep S2T_STEPS[9] = {{0, 4, 0, 0}, {1, 3, 0, 1}, {1, 5, 0, 0}, {2, 1, 1, 0}, {2, 7, 0, 0},
+                                             {3, 0, 1, 1}, {3, 2, 1, 0}, {3, 6, 0, 1}, {3, 8, 0, 0}};
+
+template <int TS>
+__global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams P) {
+  constexpr int BM = 64, BN = 256, WN = 4;
+  constexpr int IMG = BN / (TS * TS);
+  constexpr int TWP = TS + 1, HRI = TWP * TWP, HR = IMG * HRI;   // 289 / 324 input pixels per block
+  constexpr int NLB = (HR * 8 + 511) / 512;                // 5 / 6
+  constexpr int BBUF = NLB * 512 * 16;
+  static_assert(TS == 16 || TS == 8, "tile side");
+  constexpr int NLA = BM * 8 / 512;                        // 1
+  constexpr int ABUF = BM * 128;
+  constexpr int TM = BM / 32, TN = 4;
+  constexpr unsigned A_OOB = 0xFFFF0000u, B_OOB = 0xFFFFF000u;
+  __shared__ __attribute__((aligned(1024))) char smem[3 * ABUF + 2 * BBUF];
+  char* const sA = smem;
+  char* const sB = smem + 3 * ABUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const GemmOperand& X = P.B;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A.p, 0, P.A_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B.p, 0, P.B_bytes, 0x00020000);
+  // (A persistent loop over tiles, so that one tile's stores drain under the next tile's loads, was measured
+  // 20 % slower than letting the hardware start fresh blocks.)
+  const int ntotal = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int nwg = ntotal, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid % P.tiles_m, tn = bid / P.tiles_m;
+  const int m0 = tm * BM;
+  const int tX = X.W / TS, tY = X.H / TS;
+  const int img0 = (tn / (tX * tY)) * IMG, trem = tn % (tX * tY);
+  const int ty0 = (trem / tX) * TS, tx0 = (trem % tX) * TS;
+  const int nsl = P.K >> 6;
+
+  unsigned aoff[NLA], boff[NLB];
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) {
+    const int ci = i * 512 + tid, m = ci >> 3, q = (ci & 7) ^ (m & 7);
+    aoff[i] = m0 + m < P.M ? (unsigned)(m0 + m) * (unsigned)P.A.ld * 2u + (unsigned)q * 16u : A_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < NLB; ++i) {
+    const int ci = i * 512 + tid, hr = ci >> 3, q = (ci & 7) ^ (hr & 7);
+    const int il = hr / HRI, hp = hr - il * HRI;
+    const int hy = hp / TWP, hx = hp - hy * TWP;
+    const int iy = ty0 + hy, ix = tx0 + hx;                // the tile's own positions and one more row / column
+    const bool ok = hr < HR && img0 + il < X.nimg && iy < X.H && ix < X.W;
+    boff[i] = ok ? (unsigned)(((img0 + il) * X.H + iy) * X.W + ix) * (unsigned)X.ld * 2u + (unsigned)q * 16u : B_OOB;
+  }
+  char* const dA = sA + wave * 1024;
+  char* const dB = sB + wave * 1024;
+  auto issueA = [&](int slab, int step, int stage) {
+    unsigned dead = slab < nsl ? 0u : A_OOB;
+    asm volatile("" : "+v"(dead));
+    const unsigned wk = (unsigned)(S2T_STEPS[step].wtap * P.K + slab * 64) * 2u;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) glds16(rsA, (aoff[i] + wk) | dead, dA + stage * ABUF + i * 8192);
+  };
+  auto issueB = [&](int slab, int part) {
+    unsigned dead = slab < nsl ? 0u : B_OOB;
+    asm volatile("" : "+v"(dead));
+    glds16(rsB, (boff[part] + (unsigned)slab * 128u) | dead, dB + (slab & 1) * BBUF + part * 8192);
+  };
+
+  f32x4 acc[4][TM][TN];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = (lane & 15) * 128;
+  const int kq0 = lane >> 4, kq1 = 4 + (lane >> 4);
+  const int sw0 = (kq0 ^ (lane & 7)) << 4, sw1 = (kq1 ^ (lane & 7)) << 4;
+  int hr0[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nl = wn * 64 + j * 16 + (lane & 15);
+    const int il = nl / (TS * TS), p = nl % (TS * TS);
+    hr0[j] = il * HRI + (p / TS) * TWP + (p % TS);
+  }
+  bf16x8_t fa[2][TM], fb[2][TN];
+  auto load_frags = [&](int stage, int bbuf, int toff, int ks) {
+    const char* sa = sA + stage * ABUF + wm * (BM / 2) * 128 + frow;
+    const char* sb = sB + bbuf * BBUF;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + (ks ? sw1 : sw0));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int hr = hr0[j] + toff;
+      fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + hr * 128 + (((ks ? kq1 : kq0) ^ (hr & 7)) << 4));
+    }
+  };
+
+#pragma unroll
+  for (int part = 0; part < NLB; ++part) issueB(0, part);
+  issueA(0, 0, 0);
+  issueA(0, 1, 1);
+  for (int slab = 0; slab < nsl; ++slab) {
+#pragma unroll
+    for (int step = 0; step < 9; ++step) {
+      const int n_after = ((step + 7) % 9 < NLB ? 1 : 0) + NLA + ((step + 8) % 9 < NLB ? 1 : 0);
+      if (n_after == NLA) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA) : "memory");
+      else if (n_after == NLA + 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + 2) : "memory");
+      __builtin_amdgcn_s_barrier();
+      const int toff = S2T_STEPS[step].shift_i * TWP + S2T_STEPS[step].shift_j;
+      const int ph = S2T_STEPS[step].phase;
+      load_frags(step % 3, slab & 1, toff, 0);
+      if (step < 7) issueA(slab, step + 2, (step + 2) % 3);
+      else issueA(slab + 1, step - 7, (step + 2) % 3);
+      if (step < NLB) issueB(slab + 1, step);
+      load_frags(step % 3, slab & 1, toff, 1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[ph][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[ph][i][j], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  struct PhaseRowMap {
+    long long base; int Wo, HWo, nimg_left;
+    __device__ __forceinline__ bool operator()(int nl, long long& orow) const {
+      const int il = nl / (TS * TS), p = nl % (TS * TS);
+      orow = base + (long long)il * HWo + (long long)(2 * (p / TS)) * Wo + 2 * (p % TS);
+      return il < nimg_left;
+    }
+  };
+  const int Wo = 2 * X.W, HWo = 4 * X.H * X.W;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const PhaseRowMap rm{(long long)img0 * HWo + (long long)(2 * ty0 + (p >> 1)) * Wo + 2 * tx0 + (p & 1), Wo, HWo,
+                         X.nimg - img0};
+    gemm_epilogue_staged<BM, BN, WN, 3 * ABUF + 2 * BBUF>(P, acc[p], m0, rm, tn, ntotal / P.tiles_m, p, smem);
+    __syncthreads();          // the LDS staging area is reused by the next phase
+  }
 }
 
 // Tile of the convolution kernel for a problem: Cout x pixels per phase.  Small problems take 64-pixel tiles
@@ -1039,6 +1360,9 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                           ((uintptr_t)gout % 8) == 0),
                  "ried_conv2d: bad perceptual-tap arguments");
   P.E.sub = sub; P.E.ld_sub = ld_sub; P.E.gout = (bf16_t*)gout; P.E.ld_gout = ld_gout; P.E.gscale = gscale;
+  P.E.staged = !fin && !out_f32 && ldy % 8 == 0 && ((uintptr_t)y % 16) == 0 &&
+               (!mask || (ldmask % 8 == 0 && ((uintptr_t)mask % 16) == 0)) && (!y2 || ((uintptr_t)y2 % 16) == 0) &&
+               (!gout || (ld_gout % 8 == 0 && ((uintptr_t)gout % 16) == 0)) && g_forced_tile[2] != -1;
   long long a_bytes = (long long)Cout * kh * kw * Cin * 2;
   long long b_bytes = (((long long)nimg * H * W - 1) * ldx + Cin) * 2;
   RIED_CHECK_ARG(a_bytes < (long long)GLDS_OOB - (1 << 28) && b_bytes < (long long)GLDS_OOB,
@@ -1046,7 +1370,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   P.A_bytes = (unsigned)a_bytes; P.B_bytes = (unsigned)b_bytes;
   ConvTile t = choose_conv_tile(Cout, npix, phases, conv_ksteps(Cin, kh, kw, sh, sw, transposed));
   // 3x3 stride-1 layers on maps of whole 16x16 tiles: the halo-tile kernel (the input tile serves all nine taps)
-  if (g_forced_tile[0] == 0 && !fin && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 &&
+  if (g_forced_tile[0] == 0 && P.E.staged && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 &&
       Cin % 64 == 0 && H % 8 == 0 && W % 8 == 0 && a_bytes < 0xFFFF0000ll - 16384 && b_bytes < 0xFFFFF000ll - 1024 &&
       (nimg % 4 == 0 || (H % 16 == 0 && W % 16 == 0))) {
     // 16x16 tiles where the map allows; 8x8 tiles of four images otherwise (64 output channels per block there:
@@ -1056,12 +1380,25 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     P.tiles_m = ceil_div(Cout, bm);
     const int ntiles = ceil_div(nimg, 256 / (ts * ts)) * (H / ts) * (W / ts);
     // the caller sized the statistics buffer for the other kernel's rows (npix / t.bn): the spare ones are zeroed
-    if (stats && !P.E.stats_fold) P.E.stats_zero = 256 / t.bn;
+    if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = ntiles; }
     const dim3 hgrid(P.tiles_m * ntiles);
     if (ts == 8) hipLaunchKernelGGL((conv_halo_kernel<64, 8>), hgrid, dim3(512), 0, stream, P);
     else if (bm == 64 && Cin == 64) hipLaunchKernelGGL((conv_halo_kernel<64, 16, 1>), hgrid, dim3(512), 0, stream, P);
     else if (bm == 64) hipLaunchKernelGGL((conv_halo_kernel<64, 16>), hgrid, dim3(512), 0, stream, P);
     else hipLaunchKernelGGL((conv_halo_kernel<128, 16>), hgrid, dim3(512), 0, stream, P);
+    RIED_CHECK_LAUNCH("ried_conv2d");
+    return RIED_OK;
+  }
+  // data gradients of 3x3 stride-2 layers: all four phases of a tile in one block
+  if (g_forced_tile[0] == 0 && P.E.staged && transposed && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
+      Ho == 2 * H && Wo == 2 * W && Cin % 64 == 0 && a_bytes < 0xFFFF0000ll - 16384 && b_bytes < 0xFFFFF000ll - 1024 &&
+      H % 16 == 0 && W % 16 == 0) {       // (8x8 maps, four images per block: measured no faster than the general kernel)
+    const int ts = 16;
+    P.tiles_m = ceil_div(Cout, 64);
+    const int ntiles = ceil_div(nimg, 256 / (ts * ts)) * (H / ts) * (W / ts);
+    if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = 4 * ntiles; }
+    const dim3 hgrid(P.tiles_m * ntiles);
+    hipLaunchKernelGGL(conv_halo_s2t_kernel<16>, hgrid, dim3(512), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
     return RIED_OK;
   }
@@ -1073,18 +1410,21 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   }
 #define RIED_CONV_CASE(BM_, BN_, NST_)                                                                  \
   if (t.bm == BM_ && t.bn == BN_ && t.nst == NST_) {                                                    \
-    if (BN_ == 256)                                                                                     \
-      hipLaunchKernelGGL((conv_glds_kernel<BM_, BN_, NST_, 512>), grid, dim3(512), 0, stream, P);       \
-    else                                                                                                \
-      hipLaunchKernelGGL((conv_glds_kernel<BM_, (BN_ == 256 ? 128 : BN_), NST_>), grid, dim3(256), 0, stream, P); \
+    hipLaunchKernelGGL((conv_glds_kernel<BM_, BN_, NST_>), grid, dim3(256), 0, stream, P);              \
+    launched = true;                                                                                    \
+  }
+#define RIED_CONV_CASE8(BM_, BN_, NST_)                                                                 \
+  if (t.bm == BM_ && t.bn == BN_ && t.nst == NST_) {                                                    \
+    hipLaunchKernelGGL((conv_glds_kernel<BM_, BN_, NST_, 512>), grid, dim3(512), 0, stream, P);         \
     launched = true;                                                                                    \
   }
   bool launched = false;
-  RIED_CONV_CASE(128, 256, 2) RIED_CONV_CASE(128, 256, 3) RIED_CONV_CASE(64, 256, 2) RIED_CONV_CASE(64, 256, 3)
+  RIED_CONV_CASE8(128, 256, 2) RIED_CONV_CASE8(128, 256, 3) RIED_CONV_CASE8(64, 256, 2) RIED_CONV_CASE8(64, 256, 3)
   RIED_CONV_CASE(128, 128, 2) RIED_CONV_CASE(128, 128, 3) RIED_CONV_CASE(128, 64, 2) RIED_CONV_CASE(128, 64, 3)
   RIED_CONV_CASE(128, 64, 4) RIED_CONV_CASE(64, 128, 2) RIED_CONV_CASE(64, 128, 3) RIED_CONV_CASE(64, 128, 4)
   RIED_CONV_CASE(64, 64, 2) RIED_CONV_CASE(64, 64, 3) RIED_CONV_CASE(64, 64, 4)
 #undef RIED_CONV_CASE
+#undef RIED_CONV_CASE8
   RIED_CHECK_ARG(launched, "ried_conv2d: no kernel for tile %dx%dx%d", t.bm, t.bn, t.nst);
   RIED_CHECK_LAUNCH("ried_conv2d");
   return RIED_OK;

@@ -169,6 +169,43 @@ def test_conv2d_halo_tile_kernel(cin, cout, N, H, W, tr):
         close(a, g, 4e-3, what + " vs general kernel")
 
 
+@pytest.mark.parametrize("cin,cout,N,H,W", [(128, 64, 2, 16, 16), (256, 128, 1, 32, 16), (64, 72, 1, 16, 32),
+                                             (512, 64, 3, 16, 16)])
+def test_conv2d_stride2_data_gradient_halo_kernel(cin, cout, N, H, W):
+    """The data gradient of a 3x3 s2 p1 conv (H x W -> 2H x 2W) on whole tiles takes the four-phase halo kernel:
+    against torch and, with every epilogue feature the discriminator uses, against the general kernel."""
+    dy = r(N, cin, H, W, seed=60)
+    w = r(cin, cout, 3, 3, seed=61, scale=(cin * 9) ** -0.5)               # conv weight (Cout_conv=cin, Cin_conv=cout)
+    ref = F.conv_transpose2d(dy, w, None, 2, 1, output_padding=1)
+    wp = pack(w.permute(1, 0, 2, 3))
+    dyv = to_view(dy)
+    rows = ops.conv2d_stat_rows(N, 2 * H, 2 * W, cin, cout, 3, 3, 2, 2, True)
+    xfwd = r(N, cout, 2 * H, 2 * W, seed=62)                                # forward output of the layer below
+    out = {}
+    for name, force in (("halo", 0), ("general", -1)):
+        lib.ried_conv2d_force_tile(force, 0, 0)
+        try:
+            yv = ops.new_view(N, 2 * H, 2 * W, cout)
+            stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
+            ops.conv2d(dyv, wp, yv, 3, 3, 2, 2, 1, 1, transposed=True, stats=stats)
+            gv = ops.new_view(N, 2 * H, 2 * W, cout)
+            st2 = torch.full((rows, 2, cout), float("nan"), device=DEV)
+            ops.conv2d(dyv, wp, gv, 3, 3, 2, 2, 1, 1, transposed=True, mask=to_view(xfwd), mask_slope=0.2, stats=st2,
+                       stats_post=True)
+            out[name] = (from_view(yv), stats.sum(0).cpu(), from_view(gv), st2.sum(0).cpu())
+        finally:
+            lib.ried_conv2d_force_tile(0, 0, 0)
+    y, st, g, s2 = out["halo"]
+    close(y, ref, what="y")
+    close(st[1], (ref * ref).sum((0, 2, 3)), 3e-3, "sumsq over phases")
+    xm = xfwd.to(torch.bfloat16).float()
+    want = ref * torch.where(xm > 0, 1.0, 0.2)
+    close(g, want, what="masked gradient")
+    close(s2[0], want.sum((0, 2, 3)), 3e-2, "bias-gradient column sums")
+    for a, b, what in zip(out["halo"], out["general"], ("y", "stats", "masked", "column sums")):
+        close(a, b, 4e-3, what + " vs general kernel")
+
+
 def test_bn_finalize_folds_many_rows():
     """Thousands of partial rows (512x512 inference) go through the two-step reduction: same statistics."""
     g = torch.Generator().manual_seed(3)
