@@ -1230,6 +1230,140 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams 
   }
 }
 
+// ---------------------------------------------------------------------------
+// Weight gradient, LDS-DMA form.  Both operands are pixel-major (K = pixels is the slow axis), so a 16-byte DMA
+// chunk is 8 channels of one pixel and the lane-linear destination gives the [k][row] image that
+// ds_read_b64_tr_b16 wants; its XOR swizzle (TileGeom::tr_swz) is applied to the SOURCE chunk a lane fetches.
+// A = the gathered tensor (shifted by the block's tap, zero padding by out-of-range offsets), B = the tensor
+// indexed by output pixel.  Grid as the register-staged form: (tile, tap, k split); stages past the block's K
+// range fetch zeros so that the DMA count per stage is exact for the counted waits.  Measured against the
+// register-staged form on the discriminator's layers: 2-10 % faster with two stages; three stages (one block per
+// CU) are 40 % slower.
+// ---------------------------------------------------------------------------
+template <int BM, int BN, int NST>
+__device__ __forceinline__ void wgrad_glds_body(const GemmParams& P, int bx, int by, int bz, int ntiles_n,
+                                                unsigned nblocks, char* smem) {
+  using GA = TileGeom<BM>;
+  using GB = TileGeom<BN>;
+  constexpr int TM = BM / 32, TN = BN / 32;
+  constexpr int NCA = BM / 32, NCB = BN / 32;          // DMA loads per lane per stage and operand
+  constexpr int ASZ = BK * BM * 2, BSZ = BK * BN * 2, STAGE = ASZ + BSZ;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tm = bx % P.tiles_m, tn = bx / P.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const GemmOperand& G = P.A;
+  const int r0 = by / G.kw, s0 = by % G.kw;
+  const int per = ((P.K + P.splitk - 1) / P.splitk + BK - 1) / BK * BK;
+  const int kbeg = bz * per, kend = min(P.K, kbeg + per);
+  const int nsteps = (max(kend - kbeg, 0) + BK - 1) / BK;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A.p, 0, P.A_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B.p, 0, P.B_bytes, 0x00020000);
+  // A: LDS chunk (k = kA + KR*i, slot) <- channels (slot ^ swizzle(k)) * 8 of that pixel; the swizzle is the same
+  // for every i (KR is a multiple of 16)
+  const int kA = tid / GA::CPR, slotA = tid % GA::CPR;
+  const int chA = m0 + ((slotA * 8) ^ GA::tr_swz(kA));
+  unsigned deadA = chA < P.M ? 0u : GLDS_OOB;
+  const unsigned colA = (unsigned)chA * 2u;
+  const int kB = tid / GB::CPR, slotB = tid % GB::CPR;
+  const int chB = n0 + ((slotB * 8) ^ GB::tr_swz(kB));
+  unsigned deadB = chB < P.N ? 0u : GLDS_OOB;
+  asm volatile("" : "+v"(deadA), "+v"(deadB));
+  const int hw = G.Ho * G.Wo;
+  int gn[NCA], gy[NCA], gx[NCA];
+#pragma unroll
+  for (int i = 0; i < NCA; ++i) {
+    const int k = kbeg + kA + GA::KR * i;
+    const int n = k / hw, r2 = k - n * hw;
+    gn[i] = n; gy[i] = r2 / G.Wo; gx[i] = r2 - (r2 / G.Wo) * G.Wo;
+  }
+  const int dn = BK / hw, drem = BK - dn * hw, dy = drem / G.Wo, dx = drem - dy * G.Wo;
+  const unsigned ldg2 = (unsigned)G.ld * 2u, ldp2 = (unsigned)P.B.ld * 2u;
+  unsigned boff[NCB];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) boff[i] = (unsigned)(kbeg + kB + GB::KR * i) * ldp2 + (unsigned)chB * 2u;
+  int kcur = kbeg;
+  char* const lds_wave = smem + wave * 1024;
+  auto issue = [&](int buf) {
+    char* dst = lds_wave + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) {
+      const int hi = gy[i] * G.sh - G.ph + r0, wi = gx[i] * G.sw - G.pw + s0;
+      const bool ok = kcur + kA + GA::KR * i < kend && (unsigned)hi < (unsigned)G.H && (unsigned)wi < (unsigned)G.W;
+      unsigned bad = ok ? 0u : GLDS_OOB;
+      glds16(rsA, ((unsigned)((gn[i] * G.H + hi) * G.W + wi) * ldg2 + colA) | bad | deadA, dst + i * 4096);
+      int x = gx[i] + dx, y = gy[i] + dy, n = gn[i] + dn;
+      if (x >= G.Wo) { x -= G.Wo; ++y; }
+      if (y >= G.Ho) { y -= G.Ho; ++n; }
+      gx[i] = x; gy[i] = y; gn[i] = n;
+    }
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      unsigned bad = kcur + kB + GB::KR * i < kend ? 0u : GLDS_OOB;
+      glds16(rsB, boff[i] | bad | deadB, dst + ASZ + i * 4096);
+      boff[i] += (unsigned)BK * ldp2;
+    }
+    kcur += BK;
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  bf16x8_t fa[2][TM], fb[2][TN];
+  auto load_frags = [&](int buf, int ks) {
+    const bf16_t* sa = reinterpret_cast<const bf16_t*>(smem + buf * STAGE);
+    const bf16_t* sb = reinterpret_cast<const bf16_t*>(smem + buf * STAGE + ASZ);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<OP_PLAIN_TR, BM>(sa, wm * (BM / 2) + i * 16, lane, ks);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<OP_PLAIN_TR, BN>(sb, wn * (BN / 2) + j * 16, lane, ks);
+  };
+#pragma unroll
+  for (int st = 0; st < NST - 1; ++st) issue(st);
+  int rd = 0, wr = NST - 1;
+  for (int step = 0; step < nsteps; ++step) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NCA + NCB)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    load_frags(rd, 0);
+    issue(wr);
+    load_frags(rd, 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+    rd = rd + 1 == NST ? 0 : rd + 1;
+    wr = wr + 1 == NST ? 0 : wr + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  gemm_epilogue<BM, BN, true>(P, acc, m0, LinearRowMap{P, n0, 0, 0}, tn, 0, ntiles_n, by, bz, nblocks, smem);
+}
+
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256) void wgrad_glds_kernel(const GemmParams P) {
+  __shared__ __attribute__((aligned(1024))) char smem[NST * BK * (BM + BN) * 2];
+  wgrad_glds_body<BM, BN, NST>(P, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x / P.tiles_m,
+                               gridDim.x * gridDim.y * gridDim.z, smem);
+}
+
+template <int BM, int BN, int NST>
+__global__ __launch_bounds__(256) void wgrad_glds_jobs_kernel(const GemmParams* __restrict__ jobs,
+                                                              const int* __restrict__ map) {
+  __shared__ __attribute__((aligned(1024))) char smem[NST * BK * (BM + BN) * 2];
+  const GemmParams& P = jobs[map[2 * blockIdx.x]];
+  const int lb = map[2 * blockIdx.x + 1];
+  const int nx = P.grid[0], ny = P.grid[1];
+  const int bx = lb % nx, r = lb / nx;
+  wgrad_glds_body<BM, BN, NST>(P, bx, r % ny, r / ny, nx / P.tiles_m, nx * ny * P.grid[2], smem);
+}
+
 // Tile of the convolution kernel for a problem: Cout x pixels per phase.  Small problems take 64-pixel tiles
 // (more blocks than CUs matter more than MFMA efficiency there).
 struct ConvTile { int bm, bn, nst; };
@@ -1482,6 +1616,9 @@ static int wgrad_params(GemmParams& P, const void* g, long long ldg, int Cg, int
   bm = Cg <= 64 ? 64 : 128; bn = Cp <= 64 ? 64 : 128;    // ried_conv2d_wgrad_tiles mirrors this
   P.tiles_m = ceil_div(Cg, bm);
   P.grid[0] = P.tiles_m * ceil_div(Cp, bn); P.grid[1] = kh * kw; P.grid[2] = splitk;
+  const long long a_bytes = (((long long)nimg * H * W - 1) * ldg + Cg) * 2, b_bytes = ((npix - 1) * ldp + Cp) * 2;
+  RIED_CHECK_ARG(a_bytes < (long long)GLDS_OOB && b_bytes < (long long)GLDS_OOB, "ried_conv2d_wgrad: operand larger than 4 GiB");
+  P.A_bytes = (unsigned)a_bytes; P.B_bytes = (unsigned)b_bytes;
   return RIED_OK;
 }
 
@@ -1511,10 +1648,17 @@ extern "C" int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg,
   int rc = wgrad_params(P, g, ldg, Cg, nimg, H, W, p, ldp, Cp, Ho, Wo, kh, kw, sh, sw, ph, pw, slab, splitk, bm, bn);
   if (rc) return rc;
   dim3 grid(P.grid[0], P.grid[1], P.grid[2]);
-  if (bm == 64 && bn == 64) launch<64, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
-  else if (bm == 64) launch<64, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
-  else if (bn == 64) launch<128, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
-  else launch<128, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
+  if (g_forced_tile[0] == -3) {              // tuning hook: the register-staged form
+    if (bm == 64 && bn == 64) launch<64, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
+    else if (bm == 64) launch<64, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
+    else if (bn == 64) launch<128, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
+    else launch<128, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
+  } else {
+    if (bm == 64 && bn == 64) hipLaunchKernelGGL((wgrad_glds_kernel<64, 64, 2>), grid, dim3(256), 0, stream, P);
+    else if (bm == 64) hipLaunchKernelGGL((wgrad_glds_kernel<64, 128, 2>), grid, dim3(256), 0, stream, P);
+    else if (bn == 64) hipLaunchKernelGGL((wgrad_glds_kernel<128, 64, 2>), grid, dim3(256), 0, stream, P);
+    else hipLaunchKernelGGL((wgrad_glds_kernel<128, 128, 2>), grid, dim3(256), 0, stream, P);
+  }
   RIED_CHECK_LAUNCH("ried_conv2d_wgrad");
   return RIED_OK;
 }
@@ -1545,8 +1689,11 @@ extern "C" int ried_conv2d_wgrad_jobs(const void* jobs, const int* map, int nblo
   const GemmParams* J = (const GemmParams*)jobs;
 #define RIED_WJ(BM_, BN_)                                                                                  \
   if (bm == BM_ && bn == BN_) {                                                                            \
-    hipLaunchKernelGGL((igemm_jobs_kernel<BM_, BN_, OP_GATHER_TR, OP_PLAIN_TR>), dim3(nblocks), dim3(256), 0, \
-                       stream, J, map);                                                                    \
+    if (g_forced_tile[0] == -3)                                                                            \
+      hipLaunchKernelGGL((igemm_jobs_kernel<BM_, BN_, OP_GATHER_TR, OP_PLAIN_TR>), dim3(nblocks), dim3(256), 0, \
+                         stream, J, map);                                                                  \
+    else                                                                                                   \
+      hipLaunchKernelGGL((wgrad_glds_jobs_kernel<BM_, BN_, 2>), dim3(nblocks), dim3(256), 0, stream, J, map); \
     RIED_CHECK_LAUNCH("ried_conv2d_wgrad_jobs");                                                           \
     return RIED_OK;                                                                                        \
   }

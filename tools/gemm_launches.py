@@ -13,6 +13,9 @@ ts = TrainStep(g, d, vgg, B, 64, 64, use_graph=False)
 x, y = synth_batch(B, 64, seed=1234)
 ts.x.copy_(x.cuda()); ts.y.copy_(y.cuda())
 ts.step(); ts.step()
+if os.environ.get("FORCE_TILE"):          # e.g. "0,0,3": tuning hooks of ried_conv2d_force_tile
+    from reid_gan_amd._lib import lib
+    lib.ried_conv2d_force_tile(*[int(v) for v in os.environ["FORCE_TILE"].split(",")])
 rec = []
 orig = {k: getattr(ops, k) for k in ("conv2d", "conv2d_wgrad", "bgemm")}
 def wrap(name, fn):
