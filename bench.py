@@ -280,8 +280,9 @@ def main():
         fam = instrumented_step(ts)
         dom = max(fam, key=lambda k: fam[k]["ms"])
         a = fam[dom]["flops"] / (fam[dom]["ms"] * 1e-3)
-        names = {"conv": "conv_glds_kernel<*> (conv / transposed conv forward and data gradient)",
-                 "wgrad": "igemm_kernel / igemm_jobs_kernel<*, GATHER_TR, PLAIN_TR> (weight gradient)",
+        names = {"conv": "conv_glds_kernel<*>, conv_halo_kernel<*>, conv_halo_s2t_kernel<*> (conv / transposed conv "
+                         "forward and data gradient)",
+                 "wgrad": "wgrad_glds_kernel / wgrad_glds_jobs_kernel<*> (weight gradient)",
                  "bgemm": "igemm_kernel<*, PLAIN_*, PLAIN_*> (attention products)"}
         # HBM bytes per launch of the conv family from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the
         # gfx950 correction for wide reads, + WRITE_SIZE); the algorithmic bytes per launch are reported beside it

@@ -13,7 +13,7 @@ def load(d, counter):
 F, W = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
 out = {}
 for k in sorted(set(F) | set(W)):
-    if pat in k:
+    if any(q in k for q in pat.split(",")):
         nf, f = F.get(k, [0, 0.0]); nw, w = W.get(k, [0, 0.0])
         out[k] = {"launches": nf, "fetch_MB_per_launch_raw": f / max(nf, 1) / 1024, "write_MB_per_launch": w / max(nw, 1) / 1024}
 tot_n = sum(v["launches"] for v in out.values())
