@@ -6,7 +6,8 @@ from reid_gan_amd import ops
 from reid_gan_amd._lib import lib
 
 # (N, H, W, Cin, Cout, kh, kw, stride, transposed, count per step)
-SHAPES = [l.split() for l in open(sys.argv[1]).read().strip().splitlines()] if len(sys.argv) > 1 else None
+SHAPES = ([l.split() for l in open(sys.argv[1]).read().strip().splitlines()]
+          if len(sys.argv) > 1 and sys.argv[1] != "infer" else None)
 CONFIGS = [(128, 128, 2), (128, 64, 2), (64, 128, 2), (64, 64, 2), (64, 64, 4)]
 if os.environ.get("TUNE_CONFIGS"):
     CONFIGS = [tuple(int(v) for v in c.split("x")) for c in os.environ["TUNE_CONFIGS"].split(",")]
@@ -69,7 +70,30 @@ def gather_shapes(B=128):
     return [list(k) + [c] for k, c in seen.items()]
 
 
+def gather_infer_shapes(B=32, S=512):
+    import collections
+    import bench
+    from reid_gan_amd.synth import synth_batch
+    from reid_gan_amd.train_step import InferenceEngine
+    g, _, _ = bench.synth_states()
+    eng = InferenceEngine(g, B, S, S, use_graph=False)
+    x, y = synth_batch(B, S, seed=1234)
+    seen = collections.Counter()
+    orig = ops.conv2d
+    def rec(xx, w, yy, kh, kw, sh, sw, ph, pw, **k):
+        seen[(xx.N, xx.H, xx.W, xx.C, yy.C, kh, kw, sh, int(k.get("transposed", False)))] += 1
+        return orig(xx, w, yy, kh, kw, sh, sw, ph, pw, **k)
+    ops.conv2d = rec
+    eng.run(x.cuda(), y.cuda()); torch.cuda.synchronize()
+    ops.conv2d = orig
+    del eng
+    torch.cuda.empty_cache()
+    return [list(k) + [c] for k, c in seen.items()]
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "infer":
+        SHAPES = gather_infer_shapes()
     if SHAPES is None:
         SHAPES = gather_shapes()
     rows = []
@@ -78,4 +102,6 @@ if __name__ == "__main__":
         res, fl = run(N, H, W, Cin, Cout, kh, kw, s, tr)
         best = min(res, key=lambda k: res[k])
         line = " ".join(f"{c[0]}x{c[1]}x{c[2]}:{v:6.1f}" for c, v in res.items())
-        print(f"N{N} {H}x{W}x{Cin}->{Cout} k{kh}x{kw} s{s} tr{tr} x{cnt} | best {best} {res[best]:.1f}us {fl/res[best]/1e6:.0f}TF/s | {line}", flush=True)
+        io = 2.0 * N * (H * W * Cin + (H * W * s * s if tr else (H // s) * (W // s)) * Cout)      # x + y once, bf16
+        print(f"N{N} {H}x{W}x{Cin}->{Cout} k{kh}x{kw} s{s} tr{tr} x{cnt} | best {best} {res[best]:.1f}us {fl/res[best]/1e6:.0f}TF/s "
+              f"{io/res[best]/1e3:.0f}GB/s | {line}", flush=True)
