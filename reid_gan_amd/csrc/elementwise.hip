@@ -753,6 +753,47 @@ extern "C" int ried_pool_fwd(const void* x, long long ldx, void* y, long long ld
   return RIED_OK;
 }
 
+// MaxPool2d(2, 2) backward (even H, W: the windows tile the input).  One thread owns one WINDOW chunk: it reads the
+// four inputs and the output gradient once and writes the four input gradients - every tensor exactly once.
+__global__ __launch_bounds__(EW_THREADS) void maxpool2_bwd_kernel(const bf16_t* __restrict__ x, long long ldx,
+                                                                  const bf16_t* __restrict__ dy, long long lddy,
+                                                                  bf16_t* __restrict__ dx, long long lddx, int total,
+                                                                  int Ho, int Wo, int C, int accumulate,
+                                                                  int relu_mask) {
+  const int CC = C >> 3, W = 2 * Wo;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int po = i / CC, c = (i - po * CC) << 3;
+    const int ox = po % Wo, t = po / Wo;                   // t = n * Ho + oy
+    const long long p00 = ((long long)t * 2 * W) + 2 * ox;  // input pixel (2*oy, 2*ox) of image n
+    const long long pp[4] = {p00, p00 + 1, p00 + W, p00 + W + 1};
+    float v[4][8], d[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unpack8(ld8(x + pp[e] * ldx + c), v[e]);
+    unpack8(ld8(dy + (long long)po * lddy + c), d);
+    float g[4][8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      int best = 0;                                        // the first maximum in row-major scan order
+      float m = v[0][q];
+#pragma unroll
+      for (int e = 1; e < 4; ++e)
+        if (v[e][q] > m) { m = v[e][q]; best = e; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e][q] = (e == best && !(relu_mask && v[e][q] <= 0.f)) ? d[q] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (accumulate) {
+        float o[8];
+        unpack8(ld8(dx + pp[e] * lddx + c), o);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g[e][q] = relu_mask && v[e][q] <= 0.f ? 0.f : g[e][q] + o[q];
+      }
+      st8(dx + pp[e] * lddx + c, pack8(g[e]));
+    }
+  }
+}
+
 // dx += pool backward of dy.  x is the forward input (max modes only).
 extern "C" int ried_pool_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx,
                              int nimg, int H, int W, int C, int mode, int accumulate, int relu_mask,
@@ -769,6 +810,14 @@ extern "C" int ried_pool_bwd(const void* x, long long ldx, const void* dy, long 
     CHECK_VIEW("ried_pool_bwd", x, ldx, C);
     int Ho = mode == 0 ? (H + 2 - 3) / 2 + 1 : H / 2;
     int Wo = mode == 0 ? (W + 2 - 3) / 2 + 1 : W / 2;
+    const long long nwin = (long long)nimg * Ho * Wo * (C / 8);
+    if (mode == 1 && H % 2 == 0 && W % 2 == 0 && nwin < (1ll << 31)) {
+      hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(ew_grid(nwin, EW_THREADS)), dim3(EW_THREADS), 0, stream,
+                         (const bf16_t*)x, ldx, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, (int)nwin, Ho, Wo, C,
+                         accumulate, relu_mask);
+      RIED_CHECK_LAUNCH("ried_pool_bwd");
+      return RIED_OK;
+    }
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx,
                        (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, nimg, H, W, Ho, Wo, C, mode, accumulate, relu_mask);
   }
