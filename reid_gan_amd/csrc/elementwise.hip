@@ -150,33 +150,43 @@ __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const long long*
   const long long stride = J[3], st = J[7], sp = J[8], sg = J[9];
   const int E = taps * Cg;
   const bool contiguous = st == 1 && sg == taps && E <= WRED_MAX_ROW;
-  // 256 threads = Ew elements x KT lanes over the splits (short rows would otherwise leave most threads idle and
-  // each busy thread with a long chain of dependent-latency loads)
-  __shared__ float ksum[256];
-  const int Ew = E < 256 ? E : 256, KT = 256 / Ew;
+  // 256 threads = Ew four-element groups x KT lanes over the splits (short rows would otherwise leave most threads
+  // idle and each busy thread with a long chain of dependent-latency loads); 16-byte loads: Cg is a multiple of 8
+  __shared__ f32x4 ksum[256];
+  const int E4 = E >> 2;
+  const int Ew = E4 < 256 ? E4 : 256, KT = 256 / Ew;
   const int el = threadIdx.x % Ew, kl = threadIdx.x / Ew;
-  for (int e0 = 0; e0 < E; e0 += Ew) {
-    const int e = e0 + el;
+  for (int e0 = 0; e0 < E4; e0 += Ew) {
+    const int e = (e0 + el) << 2;
     const bool live = kl < KT && e < E;
     const int tap = live ? e / Cg : 0, g = live ? e - tap * Cg : 0;
-    float acc = 0.f;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (live) {
       const float* s = slab + ((long long)tap * Cp + p) * Cg + g;
 #pragma unroll 4
-      for (int k = kl; k < splitk; k += KT) acc += s[k * stride];
+      for (int k = kl; k < splitk; k += KT) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(s + k * stride);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+      }
     }
     if (KT > 1) {
       ksum[threadIdx.x] = acc;
       __syncthreads();
       if (live && kl == 0)
-        for (int q = 1; q < KT; ++q) acc += ksum[q * Ew + el];
+        for (int q = 1; q < KT; ++q) {
+          const f32x4 v = ksum[q * Ew + el];
+          acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+        }
       __syncthreads();
     }
     if (live && kl == 0) {
-      if (contiguous) rowbuf[g * taps + tap] = acc;
-      else {
-        float* o = out + tap * st + p * sp + g * sg;
-        *o = J[10] ? *o + acc : acc;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (contiguous) rowbuf[(g + q) * taps + tap] = acc[q];
+        else {
+          float* o = out + tap * st + p * sp + (g + q) * sg;
+          *o = J[10] ? *o + acc[q] : acc[q];
+        }
       }
     }
   }
