@@ -69,6 +69,8 @@ class _Lib:
                               ctypes.c_longlong if ret == "long long" else ctypes.c_int)
                 fn.argtypes = [_ctype_of(t) for t, _ in args]
             self._dll = dll
+            if os.environ.get("RIED_FORCE_TILE"):      # tuning hook, e.g. "0,0,-1" (see ried_conv2d_force_tile)
+                dll.ried_conv2d_force_tile(*[int(v) for v in os.environ["RIED_FORCE_TILE"].split(",")])
         return self._dll
 
     def call(self, name: str, *args):

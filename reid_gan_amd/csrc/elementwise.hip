@@ -674,61 +674,64 @@ __global__ void pool_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, bf1
 }
 
 // max-pool backward: the gradient of an output goes to the first maximal element of its window in
-// row-major scan order.  dx is accumulated (+=); one thread owns one INPUT pixel chunk, so no atomics.
-__global__ void maxpool_bwd_kernel(const bf16_t* __restrict__ x, long long ldx, const bf16_t* __restrict__ dy,
-                                   long long lddy, bf16_t* __restrict__ dx, long long lddx, int nimg, int H, int W,
-                                   int Ho, int Wo, int C, int mode, int accumulate, int relu_mask) {
+// row-major scan order.  One thread owns one INPUT pixel chunk, so no atomics.  The (at most four) windows that
+// contain the pixel and their (at most nine) elements are walked with compile-time bounds and clamped addresses,
+// so that all the loads of a thread are independent and in flight together.
+template <int K, int PAD>
+__global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const bf16_t* __restrict__ x, long long ldx,
+                                                                 const bf16_t* __restrict__ dy, long long lddy,
+                                                                 bf16_t* __restrict__ dx, long long lddx, int total,
+                                                                 int H, int W, int Ho, int Wo, int C, int accumulate,
+                                                                 int relu_mask) {
+  constexpr int S = 2, NWIN = (K + S - 1) / S;             // windows per axis that can contain a pixel
   const int CC = C >> 3;
-  const int k = mode == 1 ? 2 : 3, s = 2, pad = mode == 1 ? 0 : 1;
-  long long total = (long long)nimg * H * W * CC;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    long long p = i / CC;
-    int c = (int)(i - p * CC) << 3;
-    int wx = (int)(p % W);
-    long long t = p / W;
-    int hy = (int)(t % H);
-    int n = (int)(t / H);
-    float g[8];
-    if (accumulate) unpack8(ld8(dx + p * lddx + c), g);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int p = i / CC, c = (i - p * CC) << 3;
+    const int wx = p % W, t = p / W, hy = t % H, n = t / H;
+    float g[8], me[8];
+    if (accumulate) unpack8(ld8(dx + (long long)p * lddx + c), g);
     else {
 #pragma unroll
       for (int q = 0; q < 8; ++q) g[q] = 0.f;
     }
-    float me[8];
-    unpack8(ld8(x + p * ldx + c), me);
-    // output windows that contain (hy, wx)
-    int oy_lo = max(0, (hy + pad - k + s) / s), oy_hi = min(Ho - 1, (hy + pad) / s);
-    int ox_lo = max(0, (wx + pad - k + s) / s), ox_hi = min(Wo - 1, (wx + pad) / s);
-    for (int oy = oy_lo; oy <= oy_hi; ++oy)
-      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
-        // is (hy, wx) the first maximum of window (oy, ox)?
+    unpack8(ld8(x + (long long)p * ldx + c), me);
+    const int oy0 = (hy + PAD) / S, ox0 = (wx + PAD) / S;  // the last window (per axis) that contains the pixel
+#pragma unroll
+    for (int a = 0; a < NWIN; ++a) {
+#pragma unroll
+      for (int b = 0; b < NWIN; ++b) {
+        const int oy = oy0 - a, ox = ox0 - b;
+        // window (oy, ox) exists and contains (hy, wx)?
+        const bool wok = oy >= 0 && ox >= 0 && oy < Ho && ox < Wo && oy * S - PAD + K > hy && ox * S - PAD + K > wx;
         bool win[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) win[q] = true;
-        for (int r = 0; r < k; ++r) {
-          int hi = oy * s - pad + r;
-          if ((unsigned)hi >= (unsigned)H) continue;
-          for (int z = 0; z < k; ++z) {
-            int wi = ox * s - pad + z;
-            if ((unsigned)wi >= (unsigned)W) continue;
-            if (hi == hy && wi == wx) continue;
-            bool before = hi < hy || (hi == hy && wi < wx);
-            float f[8];
-            unpack8(ld8(x + ((long long)(n * H + hi) * W + wi) * ldx + c), f);
+        for (int q = 0; q < 8; ++q) win[q] = wok;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) win[q] = win[q] && (before ? f[q] < me[q] : f[q] <= me[q]);
+        for (int r = 0; r < K; ++r) {
+#pragma unroll
+          for (int z = 0; z < K; ++z) {
+            const int hi = oy * S - PAD + r, wi = ox * S - PAD + z;
+            const bool ok = wok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W && !(hi == hy && wi == wx);
+            const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
+            float f[8];
+            unpack8(ld8(x + ((long long)(n * H + hc) * W + wc) * ldx + c), f);
+            const bool before = hi < hy || (hi == hy && wi < wx);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) win[q] = win[q] && (!ok || (before ? f[q] < me[q] : f[q] <= me[q]));
           }
         }
         float d[8];
-        unpack8(ld8(dy + ((long long)(n * Ho + oy) * Wo + ox) * lddy + c), d);
+        const int oyc = min(max(oy, 0), Ho - 1), oxc = min(max(ox, 0), Wo - 1);
+        unpack8(ld8(dy + ((long long)(n * Ho + oyc) * Wo + oxc) * lddy + c), d);
 #pragma unroll
         for (int q = 0; q < 8; ++q) g[q] += win[q] ? d[q] : 0.f;
       }
+    }
     if (relu_mask) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) g[q] = me[q] > 0.f ? g[q] : 0.f;
     }
-    st8(dx + p * lddx + c, pack8(g));
+    st8(dx + (long long)p * lddx + c, pack8(g));
   }
 }
 
@@ -845,8 +848,14 @@ extern "C" int ried_pool_bwd(const void* x, long long ldx, const void* dy, long 
       RIED_CHECK_LAUNCH("ried_pool_bwd");
       return RIED_OK;
     }
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx,
-                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, nimg, H, W, Ho, Wo, C, mode, accumulate, relu_mask);
+    RIED_CHECK_ARG((long long)nimg * H * W * (C / 8) < (1ll << 31), "ried_pool_bwd: tensor too large");
+    const int total = nimg * H * W * (C / 8);
+    if (mode == 0)
+      hipLaunchKernelGGL((maxpool_bwd_kernel<3, 1>), dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx,
+                         (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, total, H, W, Ho, Wo, C, accumulate, relu_mask);
+    else
+      hipLaunchKernelGGL((maxpool_bwd_kernel<2, 0>), dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx,
+                         (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, total, H, W, Ho, Wo, C, accumulate, relu_mask);
   }
   RIED_CHECK_LAUNCH("ried_pool_bwd");
   return RIED_OK;

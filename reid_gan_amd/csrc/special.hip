@@ -212,18 +212,22 @@ __global__ __launch_bounds__(C1_WG_THREADS, 4) void conv_c1_wgrad_kernel(const f
     }
 }
 
-__global__ void rows_add_kernel(const float* __restrict__ part, int nrows, int Wd, float* __restrict__ out) {
-  __shared__ float sh[8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
+// out[c] += sum over rows of part[r][c]: 32 columns x 32 row lanes per block, four loads in flight per lane
+__global__ __launch_bounds__(1024) void rows_add_kernel(const float* __restrict__ part, int nrows, int Wd,
+                                                        float* __restrict__ out) {
+  __shared__ float sh[32][33];
+  const int cl = threadIdx.x & 31, ty = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
   float a = 0.f;
-  if (c < Wd)
-    for (int r = ty; r < nrows; r += 8) a += part[(long long)r * Wd + c];
-  sh[ty][threadIdx.x & 31] = a;
+  if (c < Wd) {
+#pragma unroll 4
+    for (int r = ty; r < nrows; r += 32) a += part[(long long)r * Wd + c];
+  }
+  sh[ty][cl] = a;
   __syncthreads();
   if (ty == 0 && c < Wd) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x & 31];
+    for (int k = 0; k < 32; ++k) t += sh[k][cl];
     out[c] += t;
   }
 }
@@ -247,7 +251,7 @@ extern "C" int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy
   else
     hipLaunchKernelGGL(conv_c1_wgrad_kernel<64>, dim3(grid), dim3(C1_WG_THREADS), 0, stream, x, (const bf16_t*)dy, lddy,
                        nimg, H, W, Ho, Wo, stride, in_scale, in_shift, scratch);
-  hipLaunchKernelGGL(rows_add_kernel, dim3(ceil_div(Cout * 9, 32)), dim3(256), 0, stream, scratch, grid, Cout * 9, dw);
+  hipLaunchKernelGGL(rows_add_kernel, dim3(ceil_div(Cout * 9, 32)), dim3(1024), 0, stream, scratch, grid, Cout * 9, dw);
   RIED_CHECK_LAUNCH("ried_conv_c1_wgrad");
   return RIED_OK;
 }
