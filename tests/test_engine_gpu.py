@@ -285,6 +285,21 @@ def test_train_step_vs_oracle(use_graph):
     assert ts.gs.adam_step.item() == 3 and ts.ds.adam_step.item() == 6
 
 
+def test_train_step_at_128_patches():
+    """The reference's default patch size (train.py:44): larger maps through the tile-based kernels."""
+    B, H = 2, 128
+    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
+    x, y = synth_batch(B, H, seed=4321)
+    with emu():
+        ref = O.train_step(O.TrainState(gsd, dsd, vgg, lr=1e-4), x, y)
+    ts = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False)
+    ts.step(x.to(DEV), y.to(DEV))
+    got = ts.losses()
+    for k in ("dloss1", "dloss2", "gloss", "vgg", "dssim", "gen"):
+        assert abs(got[k] - ref[k]) <= 2e-2 * abs(ref[k]) + 1e-4, (k, got[k], ref[k])
+    act_close(ts.G.out.cpu(), ref["pred"], "pred", mx=2e-2, mean=5e-3)
+
+
 def test_segmented_graphs_equal_single_graph(monkeypatch):
     """With several ranks the step is captured as graph segments split at the collectives (and the side streams
     must rejoin before each split).  Here the collectives are stubbed out (identical replicas: the mean over ranks
