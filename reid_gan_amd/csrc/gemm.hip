@@ -1376,7 +1376,7 @@ extern "C" int ried_conv2d_force_tile(int bm, int bn, int nst) {
   return RIED_OK;
 }
 extern "C" int ried_bn_fold_rows();
-static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int ksteps) {
+static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int ksteps, int taps) {
   const int* forced = g_forced_tile;
   ConvTile t;
   // Measured on MI355X over the layers of the training step: two LDS stages always beat three or four (blocks per
@@ -1406,6 +1406,12 @@ static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int kstep
     // measured exception (512x512 inference, deconv1: 4 phases of 128x128 maps, 64 output channels): 383 vs 506 us
     if (phases > 1 && Cout == 64 && npix >= (1 << 19)) t.bn = 128;
   }
+  // Layers with at most 32 output channels (the narrow Inception branches, deconv2): 32-row tiles waste no MFMA
+  // rows and measured 10-30 % faster everywhere; 128 pixels per block only for multi-tap layers on large maps.
+  if (Cout <= 32) {
+    t.bm = 32; t.nst = 2;
+    t.bn = (taps > 1 && npix >= 131072) ? 128 : 64;
+  }
   if (forced[0] > 0) {
     t.bm = forced[0]; t.bn = forced[1]; t.nst = forced[2];
   }
@@ -1423,7 +1429,7 @@ extern "C" int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int Cin, int Cout
                                      int transposed) {
   long long npix = transposed ? (long long)nimg * (Ho / sh) * (Wo / sw) : (long long)nimg * Ho * Wo;
   int phases = transposed ? sh * sw : 1;
-  ConvTile t = choose_conv_tile(Cout, npix, phases, conv_ksteps(Cin, kh, kw, sh, sw, transposed));
+  ConvTile t = choose_conv_tile(Cout, npix, phases, conv_ksteps(Cin, kh, kw, sh, sw, transposed), kh * kw);
   return phases * ceil_div(npix, t.bn);
 }
 
@@ -1504,7 +1510,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   RIED_CHECK_ARG(a_bytes < (long long)GLDS_OOB - (1 << 28) && b_bytes < (long long)GLDS_OOB,
                  "ried_conv2d: operand larger than 4 GiB");
   P.A_bytes = (unsigned)a_bytes; P.B_bytes = (unsigned)b_bytes;
-  ConvTile t = choose_conv_tile(Cout, npix, phases, conv_ksteps(Cin, kh, kw, sh, sw, transposed));
+  ConvTile t = choose_conv_tile(Cout, npix, phases, conv_ksteps(Cin, kh, kw, sh, sw, transposed), kh * kw);
   // 3x3 stride-1 layers on maps of whole 16x16 tiles: the halo-tile kernel (the input tile serves all nine taps)
   if (g_forced_tile[0] == 0 && P.E.staged && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 &&
       Cin % 64 == 0 && H % 8 == 0 && W % 8 == 0 && a_bytes < 0xFFFF0000ll - 16384 && b_bytes < 0xFFFFF000ll - 1024 &&
@@ -1559,6 +1565,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   RIED_CONV_CASE(128, 128, 2) RIED_CONV_CASE(128, 128, 3) RIED_CONV_CASE(128, 64, 2) RIED_CONV_CASE(128, 64, 3)
   RIED_CONV_CASE(128, 64, 4) RIED_CONV_CASE(64, 128, 2) RIED_CONV_CASE(64, 128, 3) RIED_CONV_CASE(64, 128, 4)
   RIED_CONV_CASE(64, 64, 2) RIED_CONV_CASE(64, 64, 3) RIED_CONV_CASE(64, 64, 4)
+  RIED_CONV_CASE(32, 128, 2) RIED_CONV_CASE(32, 64, 2)
 #undef RIED_CONV_CASE
 #undef RIED_CONV_CASE8
   RIED_CHECK_ARG(launched, "ried_conv2d: no kernel for tile %dx%dx%d", t.bm, t.bn, t.nst);
