@@ -174,7 +174,11 @@ int ried_ew(int op, const void* a, long long lda, const void* y, long long ldy, 
 int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, float* scratch, ried_stream_t stream);
 long long ried_colsum_scratch_floats(int C);
 int ried_dot(const void* a, long long lda, const void* b, long long ldb, long long npix, int C, float scale, float* out,
-             ried_stream_t stream); /* out[0] += scale * sum a*b (b NULL: sum a) */
+             ried_stream_t stream); /* softmax(q^T k, dim=-1) of Self_Attn (src/rinet.py:171-174) in one pass: qkv bf16 [nimg][n][ld], q in channels
+ * [0, d), k in [d, 2d); P bf16 [nimg][n][n].  Only the (n, d) for which ried_attn_scores_softmax_supported is 1. */
+int ried_attn_scores_softmax_supported(int n, int d);
+int ried_attn_scores_softmax(const void* qkv, long long ld, int nimg, int n, int d, void* P, ried_stream_t stream);
+/* out[0] += scale * sum a*b (b NULL: sum a) */
 int ried_fill(void* out, long long ldo, long long npix, int C, const float* s, float value, ried_stream_t stream);
 int ried_softmax_fwd(const float* S, void* P, long long rows, int n, ried_stream_t stream); /* src/rinet.py:174 */
 int ried_softmax_bwd(const float* dP, const void* P, void* dS, long long rows, int n, ried_stream_t stream);

@@ -48,7 +48,7 @@ def _ctype_of(t: str):
     return _CTYPES[t]
 
 
-_VALUE_SUFFIXES = ("_rows", "_floats", "_version", "_cus", "_tiles", "_bytes")
+_VALUE_SUFFIXES = ("_rows", "_floats", "_version", "_cus", "_tiles", "_bytes", "_supported")
 
 
 class _Lib:

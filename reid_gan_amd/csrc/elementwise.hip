@@ -1161,6 +1161,77 @@ __global__ void softmax_bwd_kernel(const float* __restrict__ dP, const bf16_t* _
   for (int j = lane; j < n; j += 64) o[j] = f2bf(bf2f(p[j]) * (d[j] - dot));
 }
 
+// Attention probabilities in one pass (src/rinet.py:171-174): P[b][i][:] = softmax_j(q_i . k_j) without the
+// fp32 energies ever reaching memory.  A wave owns 16 query rows of one image and all NK keys: the MFMA
+// accumulators hold S[j][i] with i = lane % 16 and four consecutive j per lane, so the row maximum and sum are a
+// scan over the lane's registers plus two shuffles, and the bf16 probabilities leave as 8-byte pieces.  The
+// fragments (16 bytes of q or k per lane) are read straight from global memory: q and k of an image are 32 KB.
+template <int D, int NK>
+__global__ __launch_bounds__(256) void attn_scores_softmax_kernel(const bf16_t* __restrict__ qkv, long long ld,
+                                                                  bf16_t* __restrict__ Pm) {
+  constexpr int NT = NK / 16, KH = D / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long img = blockIdx.y;
+  const int i0 = blockIdx.x * 64 + wave * 16;
+  const bf16_t* base = qkv + img * NK * ld;
+  const int kc = 8 * (lane >> 4);
+  bf16x8_t fb[KH];
+#pragma unroll
+  for (int h = 0; h < KH; ++h)
+    fb[h] = *reinterpret_cast<const bf16x8_t*>(base + (long long)(i0 + (lane & 15)) * ld + h * 32 + kc);
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < KH; ++h) {
+      const bf16x8_t fa =
+          *reinterpret_cast<const bf16x8_t*>(base + (long long)(t * 16 + (lane & 15)) * ld + D + h * 32 + kc);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa, fb[h], acc[t], 0, 0, 0);
+    }
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mx = fmaxf(mx, acc[t][q]);
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float sum = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { acc[t][q] = __expf(acc[t][q] - mx); sum += acc[t][q]; }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.f / sum;
+  bf16_t* o = Pm + (img * NK + i0 + (lane & 15)) * NK + (lane >> 4) * 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    *reinterpret_cast<u32x2*>(o + t * 16) =
+        u32x2{pack2bf(acc[t][0] * inv, acc[t][1] * inv), pack2bf(acc[t][2] * inv, acc[t][3] * inv)};
+}
+
+// qkv: bf16 [nimg][n][ld] with q in channels [0, d) and k in [d, 2d); P: bf16 [nimg][n][n].
+// Supported (n, d): (256, 32) and (64, 64) - the two attention layers at 64x64 patches; returns 0 otherwise so
+// that callers can ask before planning (ried_attn_scores_softmax_supported).
+extern "C" int ried_attn_scores_softmax_supported(int n, int d) { return (n == 256 && d == 32) || (n == 64 && d == 64); }
+extern "C" int ried_attn_scores_softmax(const void* qkv, long long ld, int nimg, int n, int d, void* P,
+                                        hipStream_t stream) {
+  RIED_CHECK_ARG(qkv && P && nimg > 0, "ried_attn_scores_softmax: bad arguments");
+  RIED_CHECK_ARG(ried_attn_scores_softmax_supported(n, d), "ried_attn_scores_softmax: unsupported n=%d d=%d", n, d);
+  RIED_CHECK_ARG(ld % 8 == 0 && ld >= 2 * d && ((uintptr_t)qkv % 16) == 0 && ((uintptr_t)P % 8) == 0,
+                 "ried_attn_scores_softmax: alignment");
+  if (n == 256)
+    hipLaunchKernelGGL((attn_scores_softmax_kernel<32, 256>), dim3(n / 64, nimg), dim3(256), 0, stream,
+                       (const bf16_t*)qkv, ld, (bf16_t*)P);
+  else
+    hipLaunchKernelGGL((attn_scores_softmax_kernel<64, 64>), dim3(n / 64, nimg), dim3(256), 0, stream,
+                       (const bf16_t*)qkv, ld, (bf16_t*)P);
+  RIED_CHECK_LAUNCH("ried_attn_scores_softmax");
+  return RIED_OK;
+}
+
 extern "C" int ried_softmax_fwd(const float* S, void* P, long long rows, int n, hipStream_t stream) {
   RIED_CHECK_ARG(S && P && rows > 0 && n > 0, "ried_softmax_fwd: bad arguments");
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, stream, S, (bf16_t*)P, rows, n);

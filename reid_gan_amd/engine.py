@@ -981,8 +981,11 @@ class Attn:
         q, k, v = qkv.ptr, qkv.ptr + 2 * d, qkv.ptr + 4 * d
         ld, bs = qkv.ld, n * qkv.ld
         # S[b][i][j] = q_i . k_j : m = j (A = k), n = i (B = q)
-        ops.bgemm(k, ld, bs, 0, q, ld, bs, 0, n, n, d, N, self.S.data_ptr(), n, n * n, out_f32=True)
-        ops.softmax_fwd(self.S, self.P, N * n, n)
+        if ops.attn_scores_softmax_supported(n, d):
+            ops.attn_scores_softmax(qkv, d, self.P)
+        else:
+            ops.bgemm(k, ld, bs, 0, q, ld, bs, 0, n, n, d, N, self.S.data_ptr(), n, n * n, out_f32=True)
+            ops.softmax_fwd(self.S, self.P, N * n, n)
         # O[b][i][c] = sum_j P[i][j] v[j][c] : m = c (A = v stored [j][c]), n = i (B = P)
         ops.bgemm(v, ld, bs, 1, self.P.data_ptr(), n, n * n, 0, C, n, n, N, self.O.ptr, C, n * C)
         ops.ew(ops.EW_AXPY, self.O, self.out.v, y=x, s=st.p[self.prefix + ".gamma"])

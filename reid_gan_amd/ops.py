@@ -142,6 +142,15 @@ def wgrad_reduce(slab, splitk, taps, Cp, Cg, out: torch.Tensor, st, sp, sg, scal
     lib.ried_wgrad_reduce(_p(slab), splitk, taps, Cp, Cg, _p(out), st, sp, sg, scale, int(accumulate), _stream())
 
 
+def attn_scores_softmax_supported(n: int, d: int) -> bool:
+    return bool(lib.ried_attn_scores_softmax_supported(n, d))
+
+
+def attn_scores_softmax(qkv: View, d: int, P: torch.Tensor):
+    """P[b][i][:] = softmax_j(q_i . k_j): q = channels [0, d), k = [d, 2d) of qkv; one pass, no fp32 energies."""
+    lib.ried_attn_scores_softmax(qkv.ptr, qkv.ld, qkv.N, qkv.H * qkv.W, d, _p(P), _stream())
+
+
 def bgemm(A, lda, bsa, a_tr, B, ldb, bsb, b_tr, M, N, K, batch, out, ldc, bsc, out_f32=False, alpha=1.0,
           gamma=None, resid=None, ld_resid=0, bs_resid=0, accumulate=False):
     lib.ried_bgemm(A, lda, bsa, int(a_tr), B, ldb, bsb, int(b_tr), M, N, K, batch, out, ldc, bsc, int(out_f32),

@@ -492,6 +492,21 @@ def test_bn_small_layer_kernels(C, cin, H):
     close(from_view(yv), from_view(y3), 1e-2, "y vs three-launch")
 
 
+@pytest.mark.parametrize("n,d,C", [(256, 32, 256), (64, 64, 512)])
+def test_attention_scores_softmax(n, d, C):
+    """softmax_j(q_i . k_j) in one pass (src/rinet.py:171-174) against torch on the bf16-rounded q, k."""
+    N, side = 3, int(n ** 0.5)
+    qkv = r(N, 2 * d + C, side, side, seed=70) * 0.7
+    v = to_view(qkv)
+    qb = qkv.to(torch.bfloat16).float().permute(0, 2, 3, 1).reshape(N, n, -1)
+    ref = torch.softmax(qb[:, :, :d] @ qb[:, :, d:2 * d].transpose(1, 2), dim=-1)
+    P = torch.full((N, n, n), float("nan"), dtype=torch.bfloat16, device=DEV)
+    assert ops.attn_scores_softmax_supported(n, d) and not ops.attn_scores_softmax_supported(n, d + 8)
+    ops.attn_scores_softmax(v, d, P)
+    close(P.float().cpu(), ref, 6e-3, "P")
+    assert abs(P.float().sum(-1).cpu() - 1).max() < 2e-2
+
+
 @pytest.mark.parametrize("C,npix", [(64, 1000), (512, 37), (8, 300)])
 def test_l2norm_tap(C, npix):
     a = r(npix, C, seed=40).requires_grad_(True)
