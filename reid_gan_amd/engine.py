@@ -996,7 +996,8 @@ class Attn:
         out, xin, qkv = self.out.images(n0, n1), self.xin.images(n0, n1), self.qkv.images(n0, n1)
         O, dO = self.O.images(n0, n1), self.dO.images(n0, n1)
         gamma = st.p[self.prefix + ".gamma"]
-        ops.ew(ops.EW_COPY, out.g, xin.g)                                   # residual path (first writer of xin.g)
+        if out.g.ptr != xin.g.ptr:      # residual path (first writer of xin.g); free when the two views alias
+            ops.ew(ops.EW_COPY, out.g, xin.g)
         if wgrad:
             ops.dot(out.g, O, 1.0, st.g[self.prefix + ".gamma"])
         ops.ew(ops.EW_SCALE, out.g, dO, s=gamma)
@@ -1043,6 +1044,12 @@ class Discriminator:
         a4 = Slot(ctx.act(N, H // 8, W // 8, 512))
         a5 = Slot(ctx.act(N, H // 8, W // 8, 512))
         a6 = Slot(ctx.act(N, H // 16, W // 16, 512))
+        if grads:
+            # An attention layer's output gradient is dead once its residual path has been added to the input
+            # gradient, so the two share memory: the residual copy disappears and the layer's last data gradient
+            # accumulates in place.
+            a3.act.g = a2.act.g
+            a5.act.g = a4.act.g
         self.acts = [a0, a1, a2, a3, a4, a5, a6]
         self.layers = [
             SNConv(ctx, p + "0.conv2d", 1, 64, 1, None, a0, first=True),
