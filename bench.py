@@ -220,8 +220,8 @@ def loader_bench(batch=128, patch=64, patch_n=16, nslices=64, size=512, iters=50
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=128, help="patches per GPU")
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
