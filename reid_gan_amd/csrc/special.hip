@@ -21,7 +21,7 @@ __device__ __forceinline__ void unpack8s(const u32x4& v, float (&f)[8]) {
 //
 // One lane per output pixel: a block takes 256 consecutive pixels, each lane reads its 9 input values once
 // (neighbouring lanes read neighbouring addresses) and produces all COUT channels from weights that are uniform
-// across the wave (LDS broadcast reads).  The bf16 results go through a padded LDS tile so that the global stores
+// across the wave (scalar loads).  The bf16 results go through a padded LDS tile so that the global stores
 // are full 16-byte chunks in linear order instead of 64 scattered rows per instruction.
 #define C1_TILE 256
 __device__ __forceinline__ void c1_taps(const float* __restrict__ x, long long p, long long npix, int H, int W, int Ho,
@@ -56,31 +56,26 @@ __global__ __launch_bounds__(C1_TILE) void conv_c1_fwd_kernel(
   constexpr int ROWB = COUT * 2 + 16;                 // bytes per pixel in the LDS tile (16 of padding)
   constexpr int CC = COUT / 8;
   __shared__ __attribute__((aligned(16))) char tile[C1_TILE * ROWB];
-  __shared__ __attribute__((aligned(16))) float wl[9 * COUT + COUT];     // [t][co] / sigma, then bias
   __shared__ float red[4][2 * COUT];
   const float inv = sigma ? 1.f / sigma[0] : 1.f;
-  for (int i = threadIdx.x; i < 9 * COUT; i += C1_TILE) {
-    int t = i / COUT, co = i - t * COUT;
-    wl[i] = w[co * 9 + t] * inv;
-  }
-  for (int i = threadIdx.x; i < COUT; i += C1_TILE) wl[9 * COUT + i] = bias ? bias[i] : 0.f;
   const long long npix = (long long)nimg * Ho * Wo;
   const long long p0 = (long long)blockIdx.x * C1_TILE;
   float xv[9];
   c1_taps(x, p0 + threadIdx.x, npix, H, W, Ho, Wo, stride, in_scale, in_shift, xv);
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
   for (int cc = 0; cc < CC; ++cc) {
+    // The weights are indexed by compile-time constants off a kernel argument: they arrive through the scalar
+    // cache as SGPR operands of the FMAs (an LDS copy, broadcast-read 144 times per pixel, was what bound this
+    // kernel).  1/sigma is applied to the sums.
     float acc[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (int q = 0; q < 8; ++q) {
+      const float* wq = w + (cc * 8 + q) * 9;
+      float a = 0.f;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(&wl[t * COUT + cc * 8]);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(&wl[t * COUT + cc * 8 + 4]);
-      acc[0] += xv[t] * w0[0]; acc[1] += xv[t] * w0[1]; acc[2] += xv[t] * w0[2]; acc[3] += xv[t] * w0[3];
-      acc[4] += xv[t] * w1[0]; acc[5] += xv[t] * w1[1]; acc[6] += xv[t] * w1[2]; acc[7] += xv[t] * w1[3];
+      for (int t = 0; t < 9; ++t) a += xv[t] * wq[t];
+      acc[q] = a * inv;
     }
     if (stats) {      // per-channel sum and sum of squares of the raw results over the block's pixels
 #pragma unroll
@@ -91,7 +86,7 @@ __global__ __launch_bounds__(C1_TILE) void conv_c1_fwd_kernel(
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = acc[q] + wl[9 * COUT + cc * 8 + q];
+      float v = acc[q] + (bias ? bias[cc * 8 + q] : 0.f);
       if (act == 1) v = fmaxf(v, 0.f);
       else if (act == 2) v = v > 0.f ? v : 0.2f * v;
       acc[q] = v;
@@ -232,7 +227,7 @@ __global__ __launch_bounds__(1024) void rows_add_kernel(const float* __restrict_
   }
 }
 
-#define C1_WGRAD_MAX_ROWS 768
+#define C1_WGRAD_MAX_ROWS 512
 // dw[Cout][9] += weight gradient.  scratch: fp32 [ried_conv_c1_wgrad_scratch_floats(Cout)].
 extern "C" int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy, int nimg, int H, int W, int Cout,
                                   int stride, float in_scale, float in_shift, float* dw, float* scratch,
@@ -258,48 +253,66 @@ extern "C" int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy
 extern "C" long long ried_conv_c1_wgrad_scratch_floats(int Cout) { return (long long)C1_WGRAD_MAX_ROWS * Cout * 9; }
 
 // stride 1 data gradient: dx[h][w] (+)= scale * sum_{co,r,s} dy[h+1-r][w+1-s][co] * w[co][r][s] / sigma
-// 8 lanes per pixel (one 8-channel chunk each), reduced with shuffles.
-template <int COUT>
+// 8 lanes (one 8-channel chunk each) own a horizontal strip of PX output pixels: the 3 x (PX+2) dy pixels the
+// strip needs are loaded once and feed up to three outputs each (18 loads per 4 pixels instead of 36: the kernel
+// is bound by L2 -> L1 traffic), and the lanes' partial sums are reduced with shuffles.
+template <int COUT, int PX>
 __global__ __launch_bounds__(SP_THREADS) void conv_c1_dgrad_kernel(const bf16_t* __restrict__ dy, long long lddy,
                                                                    const float* __restrict__ w,
                                                                    const float* __restrict__ sigma,
                                                                    float* __restrict__ dx, int nimg, int H, int W,
                                                                    float scale, int accumulate) {
   constexpr int CC = COUT / 8;
-  constexpr int PPB = SP_THREADS / CC;
+  constexpr int SPB = SP_THREADS / CC;                      // strips per block pass
   __shared__ float wl[9][COUT];
   const float inv = sigma ? 1.f / sigma[0] : 1.f;
   for (int i = threadIdx.x; i < 9 * COUT; i += SP_THREADS) wl[i % 9][i / 9] = w[i] * inv;
   __syncthreads();
   const int cc = threadIdx.x % CC, c = cc * 8;
-  const int pl = threadIdx.x / CC;
-  const long long npix = (long long)nimg * H * W;
-  const long long pend = (npix + PPB - 1) / PPB * PPB;     // keep all lanes in the shuffles
-  for (long long p = (long long)blockIdx.x * PPB + pl; p < pend; p += (long long)gridDim.x * PPB) {
-    float acc = 0.f;
-    if (p < npix) {
-      int wx = (int)(p % W);
-      long long t = p / W;
-      int hy = (int)(t % H);
-      int n = (int)(t / H);
+  const int sl = threadIdx.x / CC;
+  const int WS = W / PX;                                    // strips per row (host-checked: W % PX == 0)
+  const long long nstrips = (long long)nimg * H * WS;
+  const long long send = (nstrips + SPB - 1) / SPB * SPB;   // keep all lanes in the shuffles
+  for (long long s = (long long)blockIdx.x * SPB + sl; s < send; s += (long long)gridDim.x * SPB) {
+    float acc[PX];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) acc[k] = 0.f;
+    const bool live = s < nstrips;
+    const int wx = live ? (int)(s % WS) * PX : 0;
+    const long long t = live ? s / WS : 0;
+    const int hy = (int)(t % H), n = (int)(t / H);
+    if (live) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
-        int ho = hy + 1 - r;
+        const int ho = hy + 1 - r;
         if ((unsigned)ho >= (unsigned)H) continue;
+        const bf16_t* rowp = dy + ((long long)(n * H + ho) * W) * lddy + c;
 #pragma unroll
-        for (int z = 0; z < 3; ++z) {
-          int wo = wx + 1 - z;
+        for (int j = 0; j < PX + 2; ++j) {
+          const int wo = wx - 1 + j;
           if ((unsigned)wo >= (unsigned)W) continue;
           float g[8];
-          unpack8s(*reinterpret_cast<const u32x4*>(dy + ((long long)(n * H + ho) * W + wo) * lddy + c), g);
+          unpack8s(*reinterpret_cast<const u32x4*>(rowp + (long long)wo * lddy), g);
 #pragma unroll
-          for (int q = 0; q < 8; ++q) acc += g[q] * wl[r * 3 + z][c + q];
+          for (int k = 0; k < PX; ++k) {
+            const int z = k + 2 - j;                        // dy column wo = (wx + k) + 1 - z
+            if (z < 0 || z > 2) continue;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[k] += g[q] * wl[r * 3 + z][c + q];
+          }
         }
       }
     }
 #pragma unroll
-    for (int o = CC / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (cc == 0 && p < npix) dx[p] = accumulate ? dx[p] + scale * acc : scale * acc;
+    for (int k = 0; k < PX; ++k) {
+#pragma unroll
+      for (int o = CC / 2; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+    }
+    if (cc == 0 && live) {
+      float* o = dx + (long long)(n * H + hy) * W + wx;
+#pragma unroll
+      for (int k = 0; k < PX; ++k) o[k] = accumulate ? o[k] + scale * acc[k] : scale * acc[k];
+    }
   }
 }
 
@@ -309,8 +322,12 @@ extern "C" int ried_conv_c1_dgrad(const void* dy, long long lddy, const float* w
   RIED_CHECK_ARG(lddy % 8 == 0 && lddy >= Cout && ((uintptr_t)dy % 16) == 0, "ried_conv_c1_dgrad: dy view");
   RIED_CHECK_ARG(Cout == 64, "ried_conv_c1_dgrad: Cout must be 64");
   long long npix = (long long)nimg * H * W;
-  hipLaunchKernelGGL(conv_c1_dgrad_kernel<64>, dim3(ew_grid(npix, 32, 4096)), dim3(SP_THREADS), 0, stream,
-                     (const bf16_t*)dy, lddy, w, sigma, dx, nimg, H, W, scale, accumulate);
+  if (W % 4 == 0)          // (strips of 8 measured slower: 83 vs 64 us on 256 x 64 x 64)
+    hipLaunchKernelGGL((conv_c1_dgrad_kernel<64, 4>), dim3(ew_grid(npix / 4, 32, 8192)), dim3(SP_THREADS), 0, stream,
+                       (const bf16_t*)dy, lddy, w, sigma, dx, nimg, H, W, scale, accumulate);
+  else
+    hipLaunchKernelGGL((conv_c1_dgrad_kernel<64, 1>), dim3(ew_grid(npix, 32, 8192)), dim3(SP_THREADS), 0, stream,
+                       (const bf16_t*)dy, lddy, w, sigma, dx, nimg, H, W, scale, accumulate);
   RIED_CHECK_LAUNCH("ried_conv_c1_dgrad");
   return RIED_OK;
 }

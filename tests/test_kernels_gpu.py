@@ -635,6 +635,20 @@ def test_conv_c1(cout, stride):
         close(dx.cpu() - 1.0, 0.5 * gx, 3e-3, "dx")
 
 
+@pytest.mark.parametrize("H,W,acc", [(16, 32, True), (8, 64, False), (5, 12, True), (7, 9, False)])
+def test_conv_c1_dgrad_strips(H, W, acc):
+    """Four-pixel strips when the width allows, single pixels otherwise: against torch."""
+    N = 3
+    w = r(64, 1, 3, 3, seed=80)
+    sigma = torch.tensor([1.3])
+    dy = r(N, 64, H, W, seed=81)
+    xr = torch.zeros(N, 1, H, W, requires_grad=True)
+    (gx,) = torch.autograd.grad(F.conv2d(xr, w / sigma, None, 1, 1), xr, dy.to(torch.bfloat16).float())
+    dx = torch.full((N, 1, H, W), 2.0 if acc else float("nan"), device=DEV)
+    ops.conv_c1_dgrad(to_view(dy), w.to(DEV), dx, sigma=sigma.to(DEV), scale=0.25, accumulate=acc)
+    close(dx.cpu() - (2.0 if acc else 0.0), 0.25 * gx, 2e-3, "dx")
+
+
 def test_out_conv():
     N, H = 2, 16
     x = torch.randn(N, 1, H, H, generator=torch.Generator().manual_seed(5)) * 500
