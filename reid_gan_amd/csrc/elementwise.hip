@@ -703,9 +703,10 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const bf16_t* _
         const int oy = oy0 - a, ox = ox0 - b;
         // window (oy, ox) exists and contains (hy, wx)?
         const bool wok = oy >= 0 && ox >= 0 && oy < Ho && ox < Wo && oy * S - PAD + K > hy && ox * S - PAD + K > wx;
-        bool win[8];
+        // first maximum of the window: larger than everything before it (scan order), not smaller than anything after
+        float mb[8], ma[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) win[q] = wok;
+        for (int q = 0; q < 8; ++q) { mb[q] = -INFINITY; ma[q] = -INFINITY; }
 #pragma unroll
         for (int r = 0; r < K; ++r) {
 #pragma unroll
@@ -717,9 +718,16 @@ __global__ __launch_bounds__(EW_THREADS) void maxpool_bwd_kernel(const bf16_t* _
             unpack8(ld8(x + ((long long)(n * H + hc) * W + wc) * ldx + c), f);
             const bool before = hi < hy || (hi == hy && wi < wx);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) win[q] = win[q] && (!ok || (before ? f[q] < me[q] : f[q] <= me[q]));
+            for (int q = 0; q < 8; ++q) {
+              const float v = ok ? f[q] : -INFINITY;
+              if (before) mb[q] = fmaxf(mb[q], v);
+              else ma[q] = fmaxf(ma[q], v);
+            }
           }
         }
+        bool win[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) win[q] = wok && me[q] > mb[q] && me[q] >= ma[q];
         float d[8];
         const int oyc = min(max(oy, 0), Ho - 1), oxc = min(max(ox, 0), Wo - 1);
         unpack8(ld8(dy + ((long long)(n * Ho + oyc) * Wo + oxc) * lddy + c), d);

@@ -380,9 +380,19 @@ __global__ void out_conv_bwd_kernel(const float* __restrict__ x, const bf16_t* _
     *reinterpret_cast<u32x4*>(dh + p * lddh + c) =
         u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
   }
+  // lanes with equal lane % 4 hold the same channels: butterfly over the other lane bits, one LDS add per wave
 #pragma unroll
-  for (int q = 0; q < 8; ++q) atomicAdd(&ldw[1 + c + q], s[q]);
-  if (c == 0) atomicAdd(&ldw[0], s0);
+  for (int q = 0; q < 8; ++q) {
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) s[q] += __shfl_xor(s[q], o, 64);
+  }
+#pragma unroll
+  for (int o = 4; o < 64; o <<= 1) s0 += __shfl_xor(s0, o, 64);
+  if ((threadIdx.x & 63) < 4) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) atomicAdd(&ldw[1 + c + q], s[q]);
+    if (c == 0) atomicAdd(&ldw[0], s0);
+  }
   __syncthreads();
   if (threadIdx.x < 33) atomicAdd(&dw[threadIdx.x], ldw[threadIdx.x]);
 }
@@ -402,7 +412,7 @@ extern "C" int ried_out_conv_bwd(const float* x, const void* h, long long ldh, c
                                  void* dh, long long lddh, float* dw, long long npix, hipStream_t stream) {
   RIED_CHECK_ARG(x && h && w && dout && dh && dw && npix > 0 && ldh % 8 == 0 && lddh % 8 == 0 &&
                      ((uintptr_t)h % 16) == 0 && ((uintptr_t)dh % 16) == 0, "ried_out_conv_bwd: bad arguments");
-  hipLaunchKernelGGL(out_conv_bwd_kernel, dim3(ew_grid(npix * 4, SP_THREADS * 4, 160)), dim3(SP_THREADS), 0, stream,
+  hipLaunchKernelGGL(out_conv_bwd_kernel, dim3(ew_grid(npix * 4, SP_THREADS * 4, 512)), dim3(SP_THREADS), 0, stream,
                      x, (const bf16_t*)h, ldh, w, dout, (bf16_t*)dh, lddh, dw, npix);
   RIED_CHECK_LAUNCH("ried_out_conv_bwd");
   return RIED_OK;

@@ -21,3 +21,8 @@ def t(name, f, reps=20):
 t("c1_wgrad", lambda: ops.conv_c1_wgrad(x, dy, 1, dw, scr))
 t("c1_fwd", lambda: ops.conv_c1_fwd(x, w, y, 1, bias=None, act=2))
 t("c1_dgrad", lambda: ops.conv_c1_dgrad(dy, w, dimg, accumulate=True))
+h = ops.new_view(128, 64, 64, 32); h.base.normal_()
+dh = ops.new_view(128, 64, 64, 32)
+xo = torch.randn(128, 1, 64, 64, device="cuda"); do = torch.randn(128, 1, 64, 64, device="cuda")
+wo = torch.randn(1, 33, 1, 1, device="cuda"); dwo = torch.zeros(33, device="cuda")
+t("out_conv_bwd", lambda: ops.out_conv_bwd(xo, h, wo, do, dh, dwo))
