@@ -217,6 +217,64 @@ def loader_bench(batch=128, patch=64, patch_n=16, nslices=64, size=512, iters=50
     return out
 
 
+def legacy_bench(batch=128, size=64, iters=20, cpu=True):
+    """GNet / DNet of src/networks.py:460-556: forward + backward + Adam on `batch` patches, eager launches.
+    Algorithmic MACs per 64x64 patch, forward: GNet 2.744e9 (ten 3x3 256->256 convs at 16x16 are 1.51e9 of it),
+    DNet 7.61e7; forward + both gradients = 3x (the first layers have no data gradient: < 0.1 %)."""
+    from reid_gan_amd import networks as NW
+    from reid_gan_amd.engine import State
+    from reid_gan_amd.synth import synth_state, synth_batch
+    px = size * size
+    macs = {"GNet": 64 * 9 * px + 128 * 64 * 9 * px // 4 + 256 * 128 * 9 * px // 16 + 10 * 256 * 256 * 9 * px // 16 +
+                    256 * 256 * 16 * px // 16 + 384 * 128 * 16 * px // 4 + 192 * 9 * px,
+            "DNet": 64 * 9 * px // 4 + sum((64 << i) * (128 << i) * 9 * (px >> (4 + 2 * i)) for i in range(4))}
+    x, _ = synth_batch(batch, size, seed=77)
+    x = x.cuda()
+    out = {}
+    for name, mod, plan in (("GNet", NW.GNet, NW.GNetPlan), ("DNet", NW.DNet, NW.DNetPlan)):
+        sd = synth_state([(k, tuple(v.shape)) for k, v in mod().state_dict().items()], 9)
+        st = State(sd, "cuda")
+        P = plan(st, batch, size, size)
+        dout = torch.randn_like(P.forward(x))
+
+        def step():
+            P.forward(x)
+            st.zero_grad()
+            P.backward(dout)
+            st.adam(1e-4)
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            step()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        flops = 6.0 * macs[name] * batch
+        out[name] = {"value": batch / (ms * 1e-3), "unit": "patches/s (forward + backward + Adam)", "ms_per_step": ms,
+                     "batch": batch, "patch": size,
+                     "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
+                                  "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / PEAK_MFMA_BF16}}
+        del P, st
+    if cpu:
+        from oracle import ried_oracle as O
+        xs = x[:4].cpu()
+        for name, fwd, spec in (("GNet", O.gnet_forward, O.gnet_spec()), ("DNet", O.dnet_forward, O.dnet_spec())):
+            sd = synth_state([(n, s) for n, s, _ in spec], 9)
+            sd = {k: (v.requires_grad_(True) if O.trainable(k) else v) for k, v in sd.items()}
+            t0, n = time.perf_counter(), 0
+            while time.perf_counter() - t0 < 3.0 or n < 2:
+                o = fwd(O.Params(dict(sd)), xs, True)
+                torch.autograd.grad(o.square().mean(), [v for k, v in sd.items() if O.trainable(k)])
+                n += 1
+            out[name]["cpu_baseline"] = {"value": 4 * n / (time.perf_counter() - t0), "unit": "patches/s",
+                                         "cores": torch.get_num_threads(), "kind": "port",
+                                         "sample": f"{n} forward + backward passes at batch 4, fp32, stock torch CPU ops"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -307,6 +365,7 @@ def main():
             torch.cuda.empty_cache()
             out["infer"] = infer_bench()
             out["loader"] = loader_bench(cpu=not args.no_cpu_baseline)
+            out["legacy"] = legacy_bench(cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

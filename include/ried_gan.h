@@ -130,7 +130,9 @@ int ried_bn_finalize(const float* stats, int nrows, int C, long long count, floa
 long long ried_bn_finalize_fold_floats(int C);
 int ried_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* save,
                        ried_stream_t stream);
-/* y = [relu](gamma*(x-mean)*invstd + beta) [+ y]   (the residual add of src/rinet.py:250,345,443 is the accumulate) */
+/* y = act(gamma*(x-mean)*invstd + beta) [+ y]   (the residual add of src/rinet.py:250,345,443 is the accumulate).
+ * The `relu` argument of the BatchNorm functions is an activation code: 0 none, 1 ReLU, 2 LeakyReLU(0.2),
+ * 3 Sigmoid (the last two: src/networks.py:533-542). */
 int ried_bn_apply(const void* x, long long ldx, void* y, long long ldy, long long npix, int C, const float* save,
                   const float* gamma, const float* beta, int relu, int accumulate, ried_stream_t stream);
 /* Small layers, one launch fewer (BatchNorm2d train mode, src/rinet.py:187-193,199-205): ried_bn_apply_train =
@@ -173,12 +175,14 @@ int ried_ew(int op, const void* a, long long lda, const void* y, long long ldy, 
 /* out[c] += sum_p a[p][c]; scratch: fp32 [ried_colsum_scratch_floats(C)] */
 int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, float* scratch, ried_stream_t stream);
 long long ried_colsum_scratch_floats(int C);
+/* out[0] += scale * sum a*b (b NULL: sum a) */
 int ried_dot(const void* a, long long lda, const void* b, long long ldb, long long npix, int C, float scale, float* out,
-             ried_stream_t stream); /* softmax(q^T k, dim=-1) of Self_Attn (src/rinet.py:171-174) in one pass: qkv bf16 [nimg][n][ld], q in channels
+             ried_stream_t stream);
+/* softmax(q^T k, dim=-1) of Self_Attn (src/rinet.py:171-174) in one pass: qkv bf16 [nimg][n][ld], q in channels
  * [0, d), k in [d, 2d); P bf16 [nimg][n][n].  Only the (n, d) for which ried_attn_scores_softmax_supported is 1. */
 int ried_attn_scores_softmax_supported(int n, int d);
 int ried_attn_scores_softmax(const void* qkv, long long ld, int nimg, int n, int d, void* P, ried_stream_t stream);
-/* out[0] += scale * sum a*b (b NULL: sum a) */
+/* out = s ? s[0] * value : value over a bf16 view */
 int ried_fill(void* out, long long ldo, long long npix, int C, const float* s, float value, ried_stream_t stream);
 int ried_softmax_fwd(const float* S, void* P, long long rows, int n, ried_stream_t stream); /* src/rinet.py:174 */
 int ried_softmax_bwd(const float* dP, const void* P, void* dS, long long rows, int n, ried_stream_t stream);
@@ -255,6 +259,25 @@ int ried_ssim_fwd(const float* a, const float* b, const float* ref, int nimg, in
 /* da (+)= scale * scale_dev[0] * d(sum ssim_map)/d a */
 int ried_ssim_bwd(const float* a, const float* ref, const float* gmap, int nimg, int H, int W, float scale,
                   const float* scale_dev, float* da, int accumulate, ried_stream_t stream);
+
+/* ---- legacy networks (src/networks.py:460-556) ---------------------------------------------------------------------- */
+/* GNet.conv2 = Conv2d(192, 1, 3, padding=1) with bias (src/networks.py:485,519) on a bf16 view x [nimg][H][W] with
+ * C channels (C % 8 == 0, C <= 1024); w: the fp32 master weight (1, C, 3, 3); out / dout: fp32 [nimg][H][W].
+ * _dgrad: dx (+)= data gradient (bf16 view); _wgrad: dw (1, C, 3, 3) += weight gradient.  The bias gradient is
+ * ried_sum_f32 of dout. */
+int ried_conv3_to1_fwd(const void* x, long long ldx, const float* w, const float* bias, float* out, int nimg, int H,
+                       int W, int C, ried_stream_t stream);
+int ried_conv3_to1_dgrad(const float* dout, const float* w, void* dx, long long lddx, int nimg, int H, int W, int C,
+                         int accumulate, ried_stream_t stream);
+int ried_conv3_to1_wgrad(const void* x, long long ldx, const float* dout, float* dw, int nimg, int H, int W, int C,
+                         ried_stream_t stream);
+/* Data gradient of the stride-2 form of ried_conv_c1_fwd (DNet.conv1, src/networks.py:529): dy is the view
+ * [nimg][(H-1)/2+1][(W-1)/2+1] with Cout = 64 channels, dx fp32 [nimg][H][W]. */
+int ried_conv_c1_dgrad_s2(const void* dy, long long lddy, const float* w, const float* sigma, float* dx, int nimg,
+                          int H, int W, int Cout, float scale, int accumulate, ried_stream_t stream);
+/* y += alpha * x, fp32 [n]: running_mean += momentum * bias for a Conv2d with bias in front of a train-mode
+ * BatchNorm2d (src/networks.py:468-469), whose normalised output does not depend on that bias. */
+int ried_axpy_f32(float* y, const float* x, float alpha, long long n, ried_stream_t stream);
 
 /* ---- training patches ------------------------------------------------------------------------------------------ */
 /* get_patch (src/loader.py:60-73) followed by the .float().view(-1,1,P,P) of src/train.py:136-142, on slices kept

@@ -673,3 +673,90 @@ def mpl_loss(vgg: Dict[str, Tensor], target: Tensor, prediction: Tensor) -> Tens
         _, _, h, w = a.shape
         total = total + (torch.linalg.norm(a - b, dim=1, ord=2) / float(h * w)).mean()
     return total
+
+
+# --------------------------------------------------------------------------
+# legacy networks (src/networks.py:460-556); pinned by tests/golden/legacy_*.npz
+# --------------------------------------------------------------------------
+def _legacy_act(y: Tensor, act: str) -> Tensor:
+    if act == "relu":
+        return F.relu(y)
+    if act == "leaky":
+        return F.leaky_relu(y, 0.2)
+    if act == "sigmoid":
+        return torch.sigmoid(y)
+    return y
+
+
+def legacy_conv_bn(P: Params, pre: str, x: Tensor, cin: int, cout: int, k: int, stride: int, training: bool,
+                   act: str = "relu", deconv: bool = False, round_out: bool = True) -> Tensor:
+    """Sequential(Conv2d / ConvTranspose2d with bias, BatchNorm2d[, activation]) as at src/networks.py:468-484,
+    531-542: keys <pre>.0.* (conv) and <pre>.1.* (BN).
+    With the bf16 emulation on and in train mode the conv runs without its bias, as the HIP path does: the
+    normalised output does not depend on it, only running_mean does, which gets momentum * bias afterwards."""
+    wshape = (cin, cout, k, k) if deconv else (cout, cin, k, k)
+    w = _r(P.get(pre + ".0.weight", wshape))
+    b = P.get(pre + ".0.bias", (cout,))
+    conv = F.conv_transpose2d if deconv else F.conv2d
+    drop = EMULATE_BF16 and training
+    y = conv(x, w, None if drop else b, stride, 1)
+    y = _bn_relu(P, pre + ".1", y, cout, training, relu=False, round_out=False)
+    if drop:
+        P.set(pre + ".1.running_mean", P.sd[pre + ".1.running_mean"] + BN_MOMENTUM * b.detach())
+    y = _legacy_act(y, act)
+    return _r(y) if round_out else y
+
+
+def gnet_forward(P: Params, x: Tensor, training: bool = True, acts: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """GNet.forward (src/networks.py:487-521).  The one `residual` block is applied five times, so its BatchNorm
+    running statistics advance five times per forward and its weights collect five gradient terms."""
+    t = training
+    a = {} if acts is None else acts
+    w1, b1 = P.get("conv1.0.weight", (64, 1, 3, 3)), P.get("conv1.0.bias", (64,))
+    a["conv1"] = c1 = _r(F.relu(F.conv2d(x, w1, b1, 1, 1)))          # fp32 weights on the raw image
+    a["layer1"] = l1 = legacy_conv_bn(P, "layer1", c1, 64, 128, 3, 2, t)
+    a["layer2"] = s = legacy_conv_bn(P, "layer2", l1, 128, 256, 3, 2, t)
+    for _ in range(5):
+        w_a, b_a = _r(P.get("residual.0.weight", (256, 256, 3, 3))), P.get("residual.0.bias", (256,))
+        w_b, b_b = _r(P.get("residual.3.weight", (256, 256, 3, 3))), P.get("residual.3.bias", (256,))
+        drop = EMULATE_BF16 and t
+        h = _bn_relu(P, "residual.1", F.conv2d(s, w_a, None if drop else b_a, 1, 1), 256, t)
+        r = _bn_relu(P, "residual.4", F.conv2d(h, w_b, None if drop else b_b, 1, 1), 256, t, relu=False,
+                     round_out=False)
+        if drop:
+            P.set("residual.1.running_mean", P.sd["residual.1.running_mean"] + BN_MOMENTUM * b_a.detach())
+            P.set("residual.4.running_mean", P.sd["residual.4.running_mean"] + BN_MOMENTUM * b_b.detach())
+        a["residual"] = r
+        s = _r(r + s)
+    a["deconv1"] = d1 = legacy_conv_bn(P, "deconv1", s, 256, 256, 4, 2, t, deconv=True)
+    a["deconv2"] = d2 = legacy_conv_bn(P, "deconv2", torch.cat([l1, d1], 1), 384, 128, 4, 2, t, deconv=True)
+    w2, b2 = P.get("conv2.weight", (1, 192, 3, 3)), P.get("conv2.bias", (1,))
+    a["out"] = out = F.conv2d(torch.cat([c1, d2], 1), w2, b2, 1, 1)   # fp32 weights, fp32 result
+    return out
+
+
+def dnet_forward(P: Params, x: Tensor, training: bool = True, acts: Optional[Dict[str, Tensor]] = None) -> Tensor:
+    """DNet.forward (src/networks.py:544-556): (B,1,H,W) -> (B,1024,H/32,W/32) in (0, 1)."""
+    a = {} if acts is None else acts
+    w1, b1 = P.get("conv1.0.weight", (64, 1, 3, 3)), P.get("conv1.0.bias", (64,))
+    a["conv1"] = h = _r(F.leaky_relu(F.conv2d(x, w1, b1, 2, 1), 0.2))
+    c = 64
+    for i in range(2, 6):
+        a[f"conv{i}"] = h = legacy_conv_bn(P, f"conv{i}", h, c, 2 * c, 3, 2, training,
+                                           act="sigmoid" if i == 5 else "leaky")
+        c *= 2
+    return h
+
+
+def gnet_spec() -> List[Tuple[str, Tuple[int, ...], str]]:
+    P = Params(spec_mode=True)
+    with torch.no_grad():
+        gnet_forward(P, torch.zeros(2, 1, 8, 8), training=True)
+    return P.spec
+
+
+def dnet_spec() -> List[Tuple[str, Tuple[int, ...], str]]:
+    P = Params(spec_mode=True)
+    with torch.no_grad():
+        dnet_forward(P, torch.zeros(2, 1, 32, 32), training=True)
+    return P.spec

@@ -336,7 +336,23 @@ static inline int chan_grid(long long npix, int C, int iters, int cap) {
   return ew_grid(npix, ppb * iters, cap);
 }
 
-// y = relu(gamma*(x-mean)*invstd + beta) [+ y]
+// Activation after BatchNorm: 0 none, 1 ReLU (src/rinet.py:188,200), 2 LeakyReLU(0.2) and 3 Sigmoid (the legacy
+// discriminator, src/networks.py:533-542).  The codes other than 0 / 1 take the slow branch.
+__device__ __forceinline__ float bn_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return v > 0.f ? v : 0.2f * v;
+  if (act == 3) return 1.f / (1.f + __expf(-v));
+  return v;
+}
+// g * act'(v), v the pre-activation value
+__device__ __forceinline__ float bn_act_grad(float v, float g, int act) {
+  if (act == 1) return v > 0.f ? g : 0.f;
+  if (act == 2) return v > 0.f ? g : 0.2f * g;
+  if (act == 3) { float s = 1.f / (1.f + __expf(-v)); return g * s * (1.f - s); }
+  return g;
+}
+
+// y = act(gamma*(x-mean)*invstd + beta) [+ y]
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
     const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy, long long npix, int C,
     const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
@@ -357,8 +373,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
     if (accumulate) unpack8(ld8(y + p * ldy + c), o);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = f[q] * a[q] + b[q];
-      if (relu) v = fmaxf(v, 0.f);
+      float v = bn_act(f[q] * a[q] + b[q], relu);
       f[q] = accumulate ? v + o[q] : v;
     }
     st8(y + p * ldy + c, pack8(f));
@@ -405,7 +420,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         float d = xv[q] - mean[q];
-        float gg = (!relu || d * a[q] + b[q] > 0.f) ? g[q] : 0.f;
+        float gg = bn_act_grad(d * a[q] + b[q], g[q], relu);
         s1[q] += gg; s2[q] += gg * (d * istd[q]);
       }
     }
@@ -453,7 +468,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       float d = xv[q] - mean[q];
-      float gg = (!relu || d * a[q] + b[q] > 0.f) ? g[q] : 0.f;
+      float gg = bn_act_grad(d * a[q] + b[q], g[q], relu);
       g[q] = a[q] * (gg - m1[q] - d * istd[q] * m2[q]);
     }
     st8(dx + p * lddx + c, pack8(g));
@@ -601,8 +616,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_train_kernel(
     if (accumulate) unpack8(ld8(y + p * ldy + c), o);
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = f[q] * a[q] + b[q];
-      if (relu) v = fmaxf(v, 0.f);
+      float v = bn_act(f[q] * a[q] + b[q], relu);
       f[q] = accumulate ? v + o[q] : v;
     }
     st8(y + p * ldy + c, pack8(f));

@@ -415,11 +415,19 @@ class ConvBN:
     (a channel slice of the consumer's input buffer), optionally adding onto what is there (residual sum)."""
 
     def __init__(self, ctx: Ctx, prefix: str, cin, cout, k, stride, pad, xin: Slot, out: Slot, deconv=False,
-                 accumulate=False, need_dx=True, conv_key=None, bn_key=None):
+                 accumulate=False, need_dx=True, conv_key=None, bn_key=None, bias=False, act=1, shared=False,
+                 wgrad_out: Optional[torch.Tensor] = None):
+        """bias / act / shared / wgrad_out serve the legacy networks (src/networks.py:466-542): a conv bias in front
+        of the BatchNorm (train mode: it only shifts running_mean), the activation code of ops.bn_apply, layers
+        applied several times per forward (BatchNorm and bias gradients then add onto the state's), and a
+        private buffer for this use's weight gradient."""
         self.ctx, self.prefix, self.lane = ctx, prefix, ctx.build_lane
         conv_key = conv_key or (prefix + (".deconv" if deconv else ".conv"))
         self.bn = bn_key or (prefix + ".bn")
-        self.core = ConvCore(ctx, conv_key + ".weight", cin, cout, k, stride, pad, deconv, xin, need_dx)
+        self.bias_key = conv_key + ".bias" if bias else None
+        self.act, self.shared = act, shared
+        self.core = ConvCore(ctx, conv_key + ".weight", cin, cout, k, stride, pad, deconv, xin, need_dx,
+                             wgrad_out=wgrad_out)
         c = self.core
         assert out.shape == (c.N, c.Ho, c.Wo, cout), (prefix, out.shape, (c.N, c.Ho, c.Wo, cout))
         self.out, self.accumulate = out, accumulate
@@ -435,6 +443,8 @@ class ConvBN:
         self.draw: Optional[View] = None
         if ctx.grads:
             ctx.need_f32(ops.bn_backward_scratch_floats(cout))
+            if bias:
+                ctx.need_f32(ops.colsum_scratch_floats(cout))
             # the gradient w.r.t. the conv output keeps its own buffer, so that the weight gradient can wait for
             # the grouped launch at the end of the backward pass
             self.draw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
@@ -442,23 +452,29 @@ class ConvBN:
 
     def forward(self):
         ctx, c, st = self.ctx, self.core, self.ctx.st
+        # A conv bias in front of a train-mode BatchNorm cancels in the normalised output: the conv runs without
+        # it and running_mean, the one place it shows, gets momentum * bias afterwards.
         if self.sliced:
             c.conv(self.raw, stats=self.stats, stats_post=2)
             ops.bn_apply_train(self.raw, self.out.v, self.stats, self.stat_rows, self.save,
                                st.p[self.bn + ".weight"], st.p[self.bn + ".bias"], st.b[self.bn + ".running_mean"],
-                               st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"], relu=True,
+                               st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"], relu=self.act,
                                accumulate=self.accumulate)
+            if self.bias_key:
+                ops.axpy_f32(st.b[self.bn + ".running_mean"], st.p[self.bias_key], 0.1)
             return
         if ctx.training:
             c.conv(self.raw, stats=self.stats)
             ops.bn_finalize(self.stats, self.stat_rows, c.cout, self.raw.npix, self.save,
                             st.b[self.bn + ".running_mean"],
                             st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"], fold=self.fold)
+            if self.bias_key:
+                ops.axpy_f32(st.b[self.bn + ".running_mean"], st.p[self.bias_key], 0.1)
         else:
-            c.conv(self.raw)
+            c.conv(self.raw, bias=st.p[self.bias_key] if self.bias_key else None)
             ops.bn_eval_stats(st.b[self.bn + ".running_mean"], st.b[self.bn + ".running_var"], c.cout, self.save)
         ops.bn_apply(self.raw, self.out.v, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
-                     relu=True, accumulate=self.accumulate)
+                     relu=self.act, accumulate=self.accumulate)
 
     def backward(self):
         """Reads out.g; writes weight / BN gradients; accumulates into xin.g when need_dx."""
@@ -470,7 +486,10 @@ class ConvBN:
         ctx, c, st = self.ctx, self.core, self.ctx.st
         draw = self.draw
         ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
-                        ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=True)
+                        ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=self.act,
+                        accumulate=self.shared)
+        if self.bias_key:        # zero up to rounding in train mode, as in torch's autograd
+            ops.colsum(draw, st.g[self.bias_key], ctx.f32s[self.lane])
         c.wgrad(draw)
 
     def backward_input(self):

@@ -271,6 +271,9 @@ def bn_eval_stats(rm, rv, C, save, eps=1e-5):
     lib.ried_bn_eval_stats(_p(rm), _p(rv), C, eps, _p(save), _stream())
 
 
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3     # the `relu` argument of the bn_* calls takes these too
+
+
 def bn_apply(x: View, y: View, save, gamma, beta, relu=True, accumulate=False):
     lib.ried_bn_apply(x.ptr, x.ld, y.ptr, y.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta), int(relu),
                       int(accumulate), _stream())
@@ -394,6 +397,30 @@ def conv_c1_wgrad(x: torch.Tensor, dy: View, stride, dw: torch.Tensor, scratch: 
 def conv_c1_dgrad(dy: View, w, dx: torch.Tensor, sigma=None, scale=1.0, accumulate=False):
     lib.ried_conv_c1_dgrad(dy.ptr, dy.ld, _p(w), _p(sigma), _p(dx), dy.N, dy.H, dy.W, dy.C, scale, int(accumulate),
                            _stream())
+
+
+def conv_c1_dgrad_s2(dy: View, w, dx: torch.Tensor, sigma=None, scale=1.0, accumulate=False):
+    """dx: fp32 (N,1,H,W) image gradient of the stride-2 one-channel conv whose output gradient is dy."""
+    lib.ried_conv_c1_dgrad_s2(dy.ptr, dy.ld, _p(w), _p(sigma), _p(dx), dx.shape[0], dx.shape[-2], dx.shape[-1], dy.C,
+                              scale, int(accumulate), _stream())
+
+
+def conv3_to1_fwd(x: View, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor):
+    """out fp32 (N,1,H,W) = Conv2d(C, 1, 3, padding=1)(x) with the fp32 master weight (1,C,3,3)."""
+    lib.ried_conv3_to1_fwd(x.ptr, x.ld, _p(w), _p(bias), _p(out), x.N, x.H, x.W, x.C, _stream())
+
+
+def conv3_to1_dgrad(dout: torch.Tensor, w: torch.Tensor, dx: View, accumulate=False):
+    lib.ried_conv3_to1_dgrad(_p(dout), _p(w), dx.ptr, dx.ld, dx.N, dx.H, dx.W, dx.C, int(accumulate), _stream())
+
+
+def conv3_to1_wgrad(x: View, dout: torch.Tensor, dw: torch.Tensor):
+    """dw (1,C,3,3) += weight gradient."""
+    lib.ried_conv3_to1_wgrad(x.ptr, x.ld, _p(dout), _p(dw), x.N, x.H, x.W, x.C, _stream())
+
+
+def axpy_f32(y: torch.Tensor, x: torch.Tensor, alpha: float):
+    lib.ried_axpy_f32(_p(y), _p(x), alpha, y.numel(), _stream())
 
 
 def out_conv_fwd(x: torch.Tensor, h: View, w: torch.Tensor, out: torch.Tensor):

@@ -1,0 +1,202 @@
+"""GNet / DNet (src/networks.py:460-556) on the GPU: the kernels only they use against plain fp32 torch on the
+CPU, and the drop-in modules against the bf16-emulating oracle and the golden vectors made from the reference.
+
+Tolerances.  Kernels: inputs are bf16-exact, accumulation is fp32 in a different order: max |err| <= 2e-3 of the
+largest reference value (bf16 outputs: 1e-2).  Modules vs the emulating oracle: output mean |err| <= 3e-2 of
+mean |ref|, parameter gradients cosine >= 0.98 and norm within 8 %; vs the fp32 golden: output mean |err| <= 5e-2.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ried_oracle as O
+from reid_gan_amd import networks, ops
+from reid_gan_amd.synth import synth_state, synth_batch
+
+DEV = "cuda"
+GNET_SEED, DNET_SEED = 404, 505
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+def _view_from_nchw(x):
+    v = ops.new_view(x.shape[0], x.shape[2], x.shape[3], x.shape[1], DEV)
+    ops.nchw_to_nhwc(x.to(DEV).contiguous(), v)
+    return v
+
+
+def _nchw(v):
+    return v.torch().float().cpu().permute(0, 3, 1, 2)
+
+
+def _maxerr(got, ref, tol, what):
+    e = (got.double() - ref.double()).abs().max().item()
+    assert e <= tol * ref.abs().max().item() + 1e-6, f"{what}: max err {e:.4g} vs {ref.abs().max().item():.4g}"
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 16, 16, 192), (1, 9, 13, 64), (3, 8, 8, 8)])
+def test_conv3_to1_kernels(N, H, W, C):
+    r = np.random.default_rng(C + H)
+    x = _bf(torch.from_numpy(r.standard_normal((N, C, H, W)).astype(np.float32)))
+    w = torch.from_numpy((r.standard_normal((1, C, 3, 3)) / np.sqrt(9 * C)).astype(np.float32))
+    b = torch.tensor([0.3])
+    dout = torch.from_numpy(r.standard_normal((N, 1, H, W)).astype(np.float32))
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    ref = F.conv2d(xr, wr, b, 1, 1)
+    gx, gw = torch.autograd.grad((ref * dout).sum(), [xr, wr])
+    xv = _view_from_nchw(x)
+    out = torch.empty(N, 1, H, W, device=DEV)
+    ops.conv3_to1_fwd(xv, w.to(DEV), b.to(DEV), out)
+    _maxerr(out.cpu(), ref.detach(), 2e-3, "fwd")
+    dxv = ops.new_view(N, H, W, C, DEV, zero=True)
+    ops.conv3_to1_dgrad(dout.to(DEV), w.to(DEV), dxv)
+    _maxerr(_nchw(dxv), gx, 1e-2, "dgrad")
+    ops.conv3_to1_dgrad(dout.to(DEV), w.to(DEV), dxv, accumulate=True)
+    _maxerr(_nchw(dxv), 2 * gx, 2e-2, "dgrad accumulate")
+    dw = torch.full((1, C, 3, 3), 0.5, device=DEV)
+    ops.conv3_to1_wgrad(xv, dout.to(DEV), dw)
+    _maxerr(dw.cpu() - 0.5, gw, 2e-3, "wgrad")
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 16, 16), (1, 9, 13), (3, 64, 64)])
+def test_conv_c1_dgrad_stride2(N, H, W):
+    r = np.random.default_rng(H * W)
+    w = torch.from_numpy((r.standard_normal((64, 1, 3, 3)) / 3).astype(np.float32))
+    x = torch.zeros(N, 1, H, W, requires_grad=True)
+    y = F.conv2d(x, w, None, 2, 1)
+    dy = _bf(torch.from_numpy(r.standard_normal(tuple(y.shape)).astype(np.float32)))
+    (gx,) = torch.autograd.grad((y * dy).sum(), [x])
+    dx = torch.full((N, 1, H, W), 7.0, device=DEV)
+    ops.conv_c1_dgrad_s2(_view_from_nchw(dy), w.to(DEV), dx)
+    _maxerr(dx.cpu(), gx, 2e-3, "dgrad s2")
+    ops.conv_c1_dgrad_s2(_view_from_nchw(dy), w.to(DEV), dx, scale=0.5, accumulate=True)
+    _maxerr(dx.cpu(), 1.5 * gx, 2e-3, "dgrad s2 accumulate")
+
+
+@pytest.mark.parametrize("act,fn", [(ops.ACT_LEAKY, lambda t: F.leaky_relu(t, 0.2)), (ops.ACT_SIGMOID, torch.sigmoid),
+                                    (ops.ACT_NONE, lambda t: t), (ops.ACT_RELU, F.relu)])
+def test_batchnorm_activation_codes(act, fn):
+    N, C, H, W = 4, 64, 8, 8
+    r = np.random.default_rng(act)
+    x = _bf(torch.from_numpy((2 * r.standard_normal((N, C, H, W)) + 0.5).astype(np.float32)))
+    gamma = torch.from_numpy((1 + 0.2 * r.standard_normal(C)).astype(np.float32))
+    beta = torch.from_numpy((0.2 * r.standard_normal(C)).astype(np.float32))
+    dy = _bf(torch.from_numpy(r.standard_normal((N, C, H, W)).astype(np.float32)))
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = fn(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    gx, gg, gb = torch.autograd.grad((ref * dy).sum(), [xr, gr, br])
+    mean, var = x.mean(dim=(0, 2, 3)), x.var(dim=(0, 2, 3), unbiased=False)
+    save = torch.cat([mean, torch.rsqrt(var + 1e-5)]).to(DEV)
+    xv, yv, dyv = _view_from_nchw(x), ops.new_view(N, H, W, C, DEV), _view_from_nchw(dy)
+    ops.bn_apply(xv, yv, save, gamma.to(DEV), beta.to(DEV), relu=act)
+    _maxerr(_nchw(yv), ref.detach(), 1e-2, "bn_apply")
+    dxv = ops.new_view(N, H, W, C, DEV)
+    scratch = torch.empty(ops.bn_backward_scratch_floats(C), device=DEV)
+    dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.bn_backward(dyv, xv, dxv, save, gamma.to(DEV), beta.to(DEV), scratch, dg, db, relu=act)
+    _maxerr(_nchw(dxv), gx, 1.5e-2, "bn_backward dx")
+    _maxerr(dg.cpu(), gg, 5e-3, "dgamma")
+    _maxerr(db.cpu(), gb, 5e-3, "dbeta")
+
+
+def test_axpy_f32():
+    y, x = torch.arange(1000, dtype=torch.float32, device=DEV), torch.ones(1000, device=DEV)
+    ops.axpy_f32(y, x, 0.25)
+    assert torch.equal(y.cpu(), torch.arange(1000, dtype=torch.float32) + 0.25)
+
+
+# --------------------------------------------------------------------------- modules
+def _rel(a, b):
+    return (a.double() - b.double()).abs().mean().item() / (b.double().abs().mean().item() + 1e-30)
+
+
+def _cos(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return (torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item(), (a.norm() / (b.norm() + 1e-30)).item()
+
+
+def _oracle(fwd, spec, seed, x, gw):
+    sd = synth_state([(n, s) for n, s, _ in spec], seed)
+    sd = {k: (v.requires_grad_(True) if O.trainable(k) else v) for k, v in sd.items()}
+    P = O.Params(sd)
+    O.set_bf16_emulation(True)
+    try:
+        xr = x.clone().requires_grad_(True)
+        out = fwd(P, xr, True)
+        names = [k for k in sd if O.trainable(k)]
+        grads = torch.autograd.grad((out * gw).sum(), [sd[k] for k in names] + [xr], allow_unused=True)
+    finally:
+        O.set_bf16_emulation(False)
+    return out.detach(), dict(zip(names, grads[:-1])), grads[-1], P
+
+
+def _check_module(m, fwd, spec, seed, x, golden, out_tol, skip_bias_noise=True, want_dx=False):
+    m.load_state_dict(synth_state([(k, tuple(v.shape)) for k, v in m.state_dict().items()], seed))
+    m = m.cuda().train()
+    xg = x.to(DEV).requires_grad_(want_dx)
+    out = m(xg)
+    gw = torch.from_numpy(np.random.default_rng(seed + 1).standard_normal(tuple(out.shape)).astype(np.float32))
+    (out * gw.to(DEV)).sum().backward()
+    ref_out, ref_g, ref_dx, P = _oracle(fwd, spec, seed, x, gw)
+    assert _rel(out.detach().cpu(), ref_out) < out_tol, ("vs emulation", _rel(out.detach().cpu(), ref_out))
+    assert _rel(out.detach().cpu(), torch.from_numpy(golden["out"])) < 5e-2, "vs the reference's output"
+    for k, p in m.named_parameters():
+        g, r = p.grad.cpu(), ref_g[k]
+        if r is None or (k.endswith(".bias") and golden["gn:" + k][0] < 1e-3):
+            # bias in front of a train-mode BatchNorm: the true gradient is zero; both sides hold rounding noise
+            assert g.abs().max().item() < 0.05 * max(1.0, gw.abs().sum().item() ** 0.5), k
+            continue
+        c, ratio = _cos(g, r)
+        assert c >= 0.98 and abs(ratio - 1) <= 0.08, (k, c, ratio)
+        assert abs(g.double().norm().item() / golden["gn:" + k][0] - 1) < 0.1, (k, "vs the reference's gradient norm")
+    sd = m.state_dict()
+    for k in golden.files:
+        if k.startswith("rs:"):
+            got, want = sd[k[3:]].cpu().double(), torch.from_numpy(golden[k]).double()
+            assert (got - want).abs().max().item() <= 2e-2 * want.abs().max().item() + 1e-3, k
+    if want_dx:
+        c, ratio = _cos(xg.grad.cpu(), ref_dx)
+        assert c >= 0.98 and abs(ratio - 1) <= 0.08, ("dx", c, ratio)
+        c, _ = _cos(xg.grad.cpu(), torch.from_numpy(golden["dx"]))
+        assert c >= 0.95, ("dx vs the reference", c)
+    return m
+
+
+def test_gnet_module(golden_dir):
+    g = np.load(os.path.join(golden_dir, "legacy_gnet_train_64.npz"))
+    x, _ = synth_batch(2, 64, seed=41)
+    m = _check_module(networks.GNet(), O.gnet_forward, O.gnet_spec(), GNET_SEED, x, g, 3e-2)
+    assert m.residual[1].num_batches_tracked.item() == 5
+    # eval mode (running statistics, conv biases applied) on a fresh module
+    e = np.load(os.path.join(golden_dir, "legacy_eval_64.npz"))
+    m2 = networks.GNet()
+    m2.load_state_dict(synth_state([(k, tuple(v.shape)) for k, v in m2.state_dict().items()], GNET_SEED))
+    m2 = m2.cuda().eval()
+    xe, _ = synth_batch(2, 64, seed=43)
+    with torch.no_grad():
+        assert _rel(m2(xe.cuda()).cpu(), torch.from_numpy(e["gnet"])) < 3e-2
+
+
+def test_dnet_module(golden_dir):
+    g = np.load(os.path.join(golden_dir, "legacy_dnet_train_64.npz"))
+    x, _ = synth_batch(4, 64, seed=42)
+    _check_module(networks.DNet(), O.dnet_forward, O.dnet_spec(), DNET_SEED, x, g, 3e-2, want_dx=True)
+    e = np.load(os.path.join(golden_dir, "legacy_eval_64.npz"))
+    m2 = networks.DNet()
+    m2.load_state_dict(synth_state([(k, tuple(v.shape)) for k, v in m2.state_dict().items()], DNET_SEED))
+    m2 = m2.cuda().eval()
+    xe, _ = synth_batch(2, 64, seed=43)
+    with torch.no_grad():
+        assert _rel(m2(xe.cuda()).cpu(), torch.from_numpy(e["dnet"])) < 3e-2
+
+
+def test_legacy_modules_refuse_the_cpu():
+    with pytest.raises(RuntimeError):
+        networks.GNet()(torch.zeros(1, 1, 16, 16))
