@@ -217,6 +217,45 @@ def loader_bench(batch=128, patch=64, patch_n=16, nslices=64, size=512, iters=50
     return out
 
 
+def prep_bench(nslices=208, size=512, iters=20, cpu=True):
+    """get_pixels_hu (src/prep.py:46-59) on one series resident in HBM: 2 B read + 2 B written per pixel."""
+    import numpy as np
+    from reid_gan_amd._lib import lib
+    r = np.random.default_rng(1)
+    stack = r.integers(0, 4096, (nslices, size, size)).astype(np.uint16)
+    raw = torch.from_numpy(stack.view(np.int16)).cuda()
+    slope = torch.ones(nslices, dtype=torch.float64, device="cuda")
+    icpt = torch.full((nslices,), -1024, dtype=torch.int32, device="cuda")
+    outp = torch.empty_like(raw)
+    s = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        lib.ried_hu_convert(raw.data_ptr(), slope.data_ptr(), icpt.data_ptr(), outp.data_ptr(), nslices, size * size, s)
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    nbytes = 4.0 * stack.size
+    out = {"metric": "512x512 slices/sec converted to HU on the device", "value": nslices / (ms * 1e-3),
+           "unit": "slices/s", "ms_per_series": ms, "slices": nslices,
+           "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                        "frac": nbytes / (ms * 1e-3) / PEAK_HBM}}
+    if cpu:
+        from oracle import ried_oracle as O
+        t0 = time.perf_counter()
+        O.get_pixels_hu(list(stack), [1.0] * nslices, [-1024.0] * nslices)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": nslices / dt, "unit": "slices/s", "cores": 1, "kind": "port",
+                               "sample": f"numpy get_pixels_hu on the same {nslices} slices, once ({dt:.2f} s)"}
+    return out
+
+
 def legacy_bench(batch=128, size=64, iters=20, cpu=True):
     """GNet / DNet of src/networks.py:460-556: forward + backward + Adam on `batch` patches, eager launches.
     Algorithmic MACs per 64x64 patch, forward: GNet 2.744e9 (ten 3x3 256->256 convs at 16x16 are 1.51e9 of it),
@@ -366,6 +405,7 @@ def main():
             out["infer"] = infer_bench()
             out["loader"] = loader_bench(cpu=not args.no_cpu_baseline)
             out["legacy"] = legacy_bench(cpu=not args.no_cpu_baseline)
+            out["prep"] = prep_bench(cpu=not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

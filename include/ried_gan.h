@@ -293,6 +293,13 @@ int ried_patch_crop(const short* slices_in, const short* slices_tg, int nslices,
                     unsigned long long first_draw, void* x_out, void* y_out, int out_f32, int* offsets_out,
                     ried_stream_t stream);
 
+/* get_pixels_hu (src/prep.py:46-59) for a stack of decoded slices resident in HBM: raw = the 16-bit stored pixel
+ * values [nslices][npix] (either signedness: the reference casts to int16 first), slope fp64 [nslices] and
+ * intercept int32 [nslices] = int16(RescaleIntercept) per slice; out int16 [nslices][npix] in Hounsfield units, the
+ * layout ried_patch_crop reads.  npix % 8 == 0. */
+int ried_hu_convert(const void* raw, const double* slope, const int* intercept, short* out, int nslices,
+                    long long npix, ried_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -760,3 +760,22 @@ def dnet_spec() -> List[Tuple[str, Tuple[int, ...], str]]:
     with torch.no_grad():
         dnet_forward(P, torch.zeros(2, 1, 32, 32), training=True)
     return P.spec
+
+
+# --------------------------------------------------------------------------
+# DICOM -> HU (src/prep.py:46-59).  The decode itself belongs to pydicom (requirements.txt pins pydicom 2.2.2),
+# which is absent here: parity of the file decode is unpinned; the arithmetic below restates prep.py line by line.
+# --------------------------------------------------------------------------
+def get_pixels_hu(pixel_arrays, slopes, intercepts):
+    """pixel_arrays: list of (H, W) stored-value arrays (uint16 or int16), slopes / intercepts: RescaleSlope /
+    RescaleIntercept per slice -> int16 (n, H, W)."""
+    import numpy as np
+    image = np.stack(pixel_arrays)
+    image = image.astype(np.int16)                               # prep.py:49
+    image[image == -2000] = 0                                    # prep.py:50
+    for i in range(len(pixel_arrays)):
+        if slopes[i] != 1:                                       # prep.py:54-56
+            image[i] = slopes[i] * image[i].astype(np.float64)
+            image[i] = image[i].astype(np.int16)
+        image[i] += np.int16(intercepts[i])                      # prep.py:57
+    return np.array(image, dtype=np.int16)

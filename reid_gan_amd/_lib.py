@@ -20,6 +20,7 @@ _CTYPES = {
     "long long": ctypes.c_longlong,
     "unsigned long long": ctypes.c_ulonglong,
     "float": ctypes.c_float,
+    "double": ctypes.c_double,
     "ried_stream_t": ctypes.c_void_p,
 }
 

@@ -74,3 +74,46 @@ extern "C" int ried_patch_crop(const short* slices_in, const short* slices_tg, i
   RIED_CHECK_LAUNCH("ried_patch_crop");
   return RIED_OK;
 }
+
+// ---------------------------------------------------------------------------
+// get_pixels_hu (src/prep.py:46-59) on a stack of decoded DICOM slices kept in HBM:
+//   v = int16(raw);  v == -2000 -> 0;  slope != 1: v = int16(slope * float64(v));  v += int16(intercept)
+// with numpy's conversions: 16-bit wrap-around for the casts and the add, truncation toward zero from float64.
+// One 16-byte chunk (8 pixels) per thread; blockIdx.y = slice, whose slope / intercept are uniform.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void hu_convert_kernel(const unsigned short* __restrict__ raw,
+                                                         const double* __restrict__ slope,
+                                                         const int* __restrict__ intercept, short* __restrict__ out,
+                                                         long long npix) {
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int s = blockIdx.y;
+  const double sl = slope[s];
+  const short ic = (short)intercept[s];
+  const unsigned short* src = raw + (long long)s * npix;
+  short* dst = out + (long long)s * npix;
+  const long long nchunk = npix >> 3;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < nchunk; i += (long long)gridDim.x * 256) {
+    s16x8 v = *reinterpret_cast<const s16x8*>(src + i * 8);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      short t = v[q];
+      if (t == -2000) t = 0;
+      if (sl != 1.0) t = (short)(int)(sl * (double)t);
+      v[q] = (short)(t + ic);
+    }
+    *reinterpret_cast<s16x8*>(dst + i * 8) = v;
+  }
+}
+
+extern "C" int ried_hu_convert(const void* raw, const double* slope, const int* intercept, short* out, int nslices,
+                               long long npix, hipStream_t stream) {
+  RIED_CHECK_ARG(raw && slope && intercept && out && nslices > 0 && npix > 0, "ried_hu_convert: bad arguments");
+  RIED_CHECK_ARG(npix % 8 == 0 && ((uintptr_t)raw % 16) == 0 && ((uintptr_t)out % 16) == 0,
+                 "ried_hu_convert: slices must hold a multiple of 8 pixels and be 16-byte aligned");
+  RIED_CHECK_ARG(nslices <= 65535, "ried_hu_convert: too many slices for one launch");
+  dim3 grid(ew_grid(npix / 8, 256, 64), nslices);
+  hipLaunchKernelGGL(hu_convert_kernel, grid, dim3(256), 0, stream, (const unsigned short*)raw, slope, intercept, out,
+                     npix);
+  RIED_CHECK_LAUNCH("ried_hu_convert");
+  return RIED_OK;
+}
