@@ -73,8 +73,10 @@ int ried_stat_rows_sum(const float* stats, int nrows, int C, float* out, ried_st
 
 int ried_conv2d_stat_rows(int nimg, int Ho, int Wo, int Cin, int Cout, int kh, int kw, int sh, int sw,
                           int transposed);
-/* tuning hook, no counterpart in the reference: force the (Cout tile, pixel tile, LDS stages) of later ried_conv2d
- * calls; bm = 0 restores the built-in choice */
+/* tuning / test hook, no counterpart in the reference: force the (Cout tile, pixel tile, LDS stages) of later
+ * ried_conv2d calls; (0, 0, 0) restores the built-in choice.  bm = -1: the general kernel with its own tile
+ * choice (no halo-tile kernels); (0, 1, 0): the halo-tile kernels even where their block count is below a CU's
+ * worth; nst = -1: no LDS-staged epilogue. */
 int ried_conv2d_force_tile(int bm, int bn, int nst);
 
 /* Weight-gradient partial sums (autograd of the convs above).  g is the tensor seen through the kernel window

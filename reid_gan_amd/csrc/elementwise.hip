@@ -652,38 +652,49 @@ extern "C" int ried_bn_apply_train(const void* x, long long ldx, void* y, long l
 // pooling / upsampling (reference: src/rinet.py:235,260,266,330,355,361,428; VGG16 MaxPool2d(2,2))
 // ---------------------------------------------------------------------------
 // mode 0: max 3x3 s2 p1   mode 1: max 2x2 s2 p0   mode 2: avg 3x3 s1 p1 (count_include_pad)
-__global__ void pool_fwd_kernel(const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy,
-                                int nimg, int H, int W, int Ho, int Wo, int C, int mode) {
+// One thread per output chunk (8 channels).  The window is walked with compile-time bounds and clamped addresses, so
+// that a thread's (up to nine) loads are independent and in flight together; index arithmetic is 32-bit.
+template <int MODE>
+__global__ __launch_bounds__(EW_THREADS) void pool_fwd_kernel(const bf16_t* __restrict__ x, long long ldx,
+                                                              bf16_t* __restrict__ y, long long ldy, int total, int H,
+                                                              int W, int Ho, int Wo, int C) {
+  constexpr int K = MODE == 1 ? 2 : 3, S = MODE == 2 ? 1 : 2, PAD = MODE == 1 ? 0 : 1;
   const int CC = C >> 3;
-  const int k = mode == 1 ? 2 : 3, s = mode == 2 ? 1 : 2, pad = mode == 1 ? 0 : 1;
-  long long total = (long long)nimg * Ho * Wo * CC;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    long long p = i / CC;
-    int c = (int)(i - p * CC) << 3;
-    int ox = (int)(p % Wo);
-    long long t = p / Wo;
-    int oy = (int)(t % Ho);
-    int n = (int)(t / Ho);
-    float acc[8];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int p = i / CC, c = (i - p * CC) << 3;
+    const int ox = p % Wo, t = p / Wo, oy = t % Ho, n = t / Ho;
+    const bf16_t* xi = x + (long long)n * H * W * ldx + c;
+    u32x4 v[K * K];
+    bool ok[K * K];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = mode == 2 ? 0.f : -INFINITY;
-    for (int r = 0; r < k; ++r) {
-      int hi = oy * s - pad + r;
-      if ((unsigned)hi >= (unsigned)H) continue;
-      for (int z = 0; z < k; ++z) {
-        int wi = ox * s - pad + z;
-        if ((unsigned)wi >= (unsigned)W) continue;
-        float f[8];
-        unpack8(ld8(x + ((long long)(n * H + hi) * W + wi) * ldx + c), f);
+    for (int r = 0; r < K; ++r) {
+      const int hi = oy * S - PAD + r;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] = mode == 2 ? acc[q] + f[q] : fmaxf(acc[q], f[q]);
+      for (int z = 0; z < K; ++z) {
+        const int wi = ox * S - PAD + z;
+        ok[r * K + z] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
+        v[r * K + z] = ld8(xi + (long long)(hc * W + wc) * ldx);
       }
     }
-    if (mode == 2) {
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = MODE == 2 ? 0.f : -INFINITY;
+#pragma unroll
+    for (int e = 0; e < K * K; ++e) {
+      float f[8];
+      unpack8(v[e], f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (MODE == 2) acc[q] += ok[e] ? f[q] : 0.f;
+        else acc[q] = ok[e] ? fmaxf(acc[q], f[q]) : acc[q];
+      }
+    }
+    if (MODE == 2) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) acc[q] *= (1.f / 9.f);
     }
-    st8(y + p * ldy + c, pack8(acc));
+    st8(y + (long long)p * ldy + c, pack8(acc));
   }
 }
 
@@ -799,8 +810,16 @@ extern "C" int ried_pool_fwd(const void* x, long long ldx, void* y, long long ld
   RIED_CHECK_ARG(mode >= 0 && mode <= 2 && nimg > 0 && H > 0 && W > 0, "ried_pool_fwd: bad arguments");
   int Ho = mode == 0 ? (H + 2 - 3) / 2 + 1 : mode == 1 ? H / 2 : H;
   int Wo = mode == 0 ? (W + 2 - 3) / 2 + 1 : mode == 1 ? W / 2 : W;
-  hipLaunchKernelGGL(pool_fwd_kernel, dim3(ew_grid((long long)nimg * Ho * Wo * (C / 8), EW_THREADS)),
-                     dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, C, mode);
+  const long long total = (long long)nimg * Ho * Wo * (C / 8);
+  RIED_CHECK_ARG(total < (1ll << 31) && (long long)H * W < (1ll << 31), "ried_pool_fwd: tensor too large");
+  const dim3 grid(ew_grid(total, EW_THREADS, 65536)), block(EW_THREADS);
+#define RIED_POOL_FWD(M)                                                                                      \
+  hipLaunchKernelGGL(pool_fwd_kernel<M>, grid, block, 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, (int)total, \
+                     H, W, Ho, Wo, C)
+  if (mode == 0) RIED_POOL_FWD(0);
+  else if (mode == 1) RIED_POOL_FWD(1);
+  else RIED_POOL_FWD(2);
+#undef RIED_POOL_FWD
   RIED_CHECK_LAUNCH("ried_pool_fwd");
   return RIED_OK;
 }

@@ -1177,7 +1177,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams 
     for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + (ks ? sw1 : sw0));
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int hr = hr0[j] + toff;
+      int hr = hr0[j] + toff;
+      asm volatile("" : "+v"(hr));      // recomputed per step: hoisted, the 9 x 8 addresses cost spills
       fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + hr * 128 + (((ks ? kq1 : kq0) ^ (hr & 7)) << 4));
     }
   };
@@ -1226,6 +1227,181 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams 
     const PhaseRowMap rm{(long long)img0 * HWo + (long long)(2 * ty0 + (p >> 1)) * Wo + 2 * tx0 + (p & 1), Wo, HWo,
                          X.nimg - img0};
     gemm_epilogue_staged<BM, BN, WN, 3 * ABUF + 2 * BBUF>(P, acc[p], m0, rm, tn, ntotal / P.tiles_m, p, smem);
+    __syncthreads();          // the LDS staging area is reused by the next phase
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ConvTranspose2d(kernel 4, stride 2, padding 1) forward (src/rinet.py:216,219,272,276 in decoder mode, :68-69;
+// src/networks.py:479-484), halo-tile form.  Output (2i+a, 2j+b) takes input (i+di, j+dj) through tap (r, s) with
+// a + 1 - r = 2 di and b + 1 - s = 2 dj: every phase (a, b) is a 2x2-tap convolution, and the four of them read
+// the same 3x3 neighbourhood.  The general kernel runs the phases as four GEMMs of four taps each and fetches the
+// input once per tap: with few output channels (the generator's last layers have 32 and 64) that is all
+// L2 -> LDS traffic and no arithmetic.  Here, as in conv_halo_s2t_kernel, a block owns 16 x 16 input positions of
+// one image and all four phases of their 32 x 32 output pixels: the 18 x 18 input tile is loaded once per
+// 64-channel slab and the sixteen (phase, tap) products of the slab are the steps of the pipeline.
+// Cin % 32 == 0: the second half of the last slab is skipped when Cin % 64 == 32 (its chunks are fetched - the
+// next pixel's channels, the next tap's weights, finite values or zeros - but never multiplied).
+// BM output channels per block (32 or 64); the weight stage always holds 64 rows (rows past Cout load as zeros).
+// ---------------------------------------------------------------------------
+struct D4Step { int phase, wtap, shift_i, shift_j; };
+__device__ constexpr D4Step D4_STEPS[16] = {
+    {0, 5, 0, 0},  {0, 7, 0, -1},  {0, 13, -1, 0}, {0, 15, -1, -1},      // a = 0, b = 0: r in {1, 3}, s in {1, 3}
+    {1, 4, 0, 1},  {1, 6, 0, 0},   {1, 12, -1, 1}, {1, 14, -1, 0},       // a = 0, b = 1: r in {1, 3}, s in {0, 2}
+    {2, 1, 1, 0},  {2, 3, 1, -1},  {2, 9, 0, 0},   {2, 11, 0, -1},       // a = 1, b = 0: r in {0, 2}, s in {1, 3}
+    {3, 0, 1, 1},  {3, 2, 1, 0},   {3, 8, 0, 1},   {3, 10, 0, 0}};       // a = 1, b = 1: r in {0, 2}, s in {0, 2}
+
+template <int BM>
+__global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P) {
+  constexpr int TS = 16, BN = 256, WN = 4, NSTEP = 16;
+  constexpr int TWP = TS + 2, HR = TWP * TWP;              // 324 input pixels per block
+  constexpr int NLB = (HR * 8 + 511) / 512;                // 6
+  constexpr int BBUF = NLB * 512 * 16;
+  constexpr int NLA = 1, ABUF = 64 * 128, NSA = 4;         // weight ring: 4 stages of 64 rows x 64 channels
+  constexpr int TM = BM / 32, TN = 4;
+  static_assert(BM == 32 || BM == 64, "output-channel tile");
+  constexpr unsigned A_OOB = 0xFFFF0000u, B_OOB = 0xFFFFF000u;
+  __shared__ __attribute__((aligned(1024))) char smem[NSA * ABUF + 2 * BBUF];
+  char* const sA = smem;
+  char* const sB = smem + NSA * ABUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const GemmOperand& X = P.B;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A.p, 0, P.A_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B.p, 0, P.B_bytes, 0x00020000);
+  const int ntotal = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int nwg = ntotal, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid % P.tiles_m, tn = bid / P.tiles_m;
+  const int m0 = tm * BM;
+  const int tX = X.W / TS, tY = X.H / TS;
+  const int img0 = tn / (tX * tY), trem = tn % (tX * tY);
+  const int ty0 = (trem / tX) * TS, tx0 = (trem % tX) * TS;
+  const int nsl = (P.K + 63) >> 6;
+  const bool half_tail = (P.K & 63) != 0;                  // Cin % 64 == 32
+
+  unsigned aoff[NLA], boff[NLB];
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) {
+    const int ci = i * 512 + tid, m = ci >> 3, q = (ci & 7) ^ (m & 7);
+    aoff[i] = m0 + m < P.M ? (unsigned)(m0 + m) * (unsigned)P.A.ld * 2u + (unsigned)q * 16u : A_OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < NLB; ++i) {
+    const int ci = i * 512 + tid, hr = ci >> 3, q = (ci & 7) ^ (hr & 7);
+    const int hy = hr / TWP, hx = hr - hy * TWP;
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;        // the tile's own positions and a ring of one around them
+    const bool ok = hr < HR && (unsigned)iy < (unsigned)X.H && (unsigned)ix < (unsigned)X.W;
+    boff[i] = ok ? (unsigned)((img0 * X.H + iy) * X.W + ix) * (unsigned)X.ld * 2u + (unsigned)q * 16u : B_OOB;
+  }
+  char* const dA = sA + wave * 1024;
+  char* const dB = sB + wave * 1024;
+  auto issueA = [&](int slab, int step, int stage) {
+    unsigned dead = slab < nsl ? 0u : A_OOB;
+    asm volatile("" : "+v"(dead));
+    const unsigned wk = (unsigned)(D4_STEPS[step].wtap * P.K + slab * 64) * 2u;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) glds16(rsA, (aoff[i] + wk) | dead, dA + stage * ABUF + i * 8192);
+  };
+  auto issueB = [&](int slab, int part) {
+    unsigned dead = slab < nsl ? 0u : B_OOB;
+    asm volatile("" : "+v"(dead));
+    glds16(rsB, (boff[part] + (unsigned)slab * 128u) | dead, dB + (slab & 1) * BBUF + part * 8192);
+  };
+
+  f32x4 acc[4][TM][TN];
+#pragma unroll
+  for (int p = 0; p < 4; ++p)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[p][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = (lane & 15) * 128;
+  const int kq0 = lane >> 4, kq1 = 4 + (lane >> 4);
+  const int sw0 = (kq0 ^ (lane & 7)) << 4, sw1 = (kq1 ^ (lane & 7)) << 4;
+  int hr0[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int p = wn * 64 + j * 16 + (lane & 15);
+    hr0[j] = (p / TS + 1) * TWP + (p % TS) + 1;
+  }
+  bf16x8_t fa[2][TM], fb[2][TN];
+  auto load_frags = [&](int stage, int bbuf, int toff, int ks) {
+    const char* sa = sA + stage * ABUF + wm * (BM / 2) * 128 + frow;
+    const char* sb = sB + bbuf * BBUF;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + (ks ? sw1 : sw0));
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int hr = hr0[j] + toff;
+      // recomputed per step: hoisted out of the slab loop, the 16 x 8 distinct addresses would not fit the
+      // register file beside the four accumulator sets
+      asm volatile("" : "+v"(hr));
+      fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + hr * 128 + (((ks ? kq1 : kq0) ^ (hr & 7)) << 4));
+    }
+  };
+
+#pragma unroll
+  for (int part = 0; part < NLB; ++part) issueB(0, part);
+  issueA(0, 0, 0);
+  issueA(0, 1, 1);
+  issueA(0, 2, 2);
+  for (int slab = 0; slab < nsl; ++slab) {
+    const bool both = !(half_tail && slab == nsl - 1);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      // still in flight after this wait: what was issued after this step's weights (three steps ago): the
+      // weights of the next two steps and up to three parts of the next slab's input tile.  (A block is alone on
+      // its CU and a step is only 8-16 MFMAs per wave: three steps of weights in flight, not two, cover the L2
+      // latency.)
+      const int n_after = 2 * NLA + ((step + NSTEP - 3) % NSTEP < NLB ? 1 : 0) +
+                          ((step + NSTEP - 2) % NSTEP < NLB ? 1 : 0) + ((step + NSTEP - 1) % NSTEP < NLB ? 1 : 0);
+      if (n_after == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (n_after == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (n_after == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int toff = D4_STEPS[step].shift_i * TWP + D4_STEPS[step].shift_j;
+      const int ph = D4_STEPS[step].phase;
+      load_frags(step % NSA, slab & 1, toff, 0);
+      if (step < NSTEP - 3) issueA(slab, step + 3, (step + 3) % NSA);
+      else issueA(slab + 1, step + 3 - NSTEP, (step + 3) % NSA);
+      if (step < NLB) issueB(slab + 1, step);
+      if (both) load_frags(step % NSA, slab & 1, toff, 1);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[ph][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[ph][i][j], 0, 0, 0);
+      if (both) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[ph][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[ph][i][j], 0, 0, 0);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  struct PhaseRowMap {
+    long long base; int Wo;
+    __device__ __forceinline__ bool operator()(int nl, long long& orow) const {
+      orow = base + (long long)(2 * (nl / TS)) * Wo + 2 * (nl % TS);
+      return true;
+    }
+  };
+  const int Wo = 2 * X.W, HWo = 4 * X.H * X.W;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const PhaseRowMap rm{(long long)img0 * HWo + (long long)(2 * ty0 + (p >> 1)) * Wo + 2 * tx0 + (p & 1), Wo};
+    gemm_epilogue_staged<BM, BN, WN, NSA * ABUF + 2 * BBUF>(P, acc[p], m0, rm, tn, ntotal / P.tiles_m, p, smem);
     __syncthreads();          // the LDS staging area is reused by the next phase
   }
 }
@@ -1541,6 +1717,23 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = 4 * ntiles; }
     const dim3 hgrid(P.tiles_m * ntiles);
     hipLaunchKernelGGL(conv_halo_s2t_kernel<16>, hgrid, dim3(512), 0, stream, P);
+    RIED_CHECK_LAUNCH("ried_conv2d");
+    return RIED_OK;
+  }
+  // ConvTranspose2d(4, 2, 1) forward on maps of whole 16x16 tiles: all four phases of a tile in one block
+  if (g_forced_tile[0] == 0 && P.E.staged && transposed && kh == 4 && kw == 4 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
+      Ho == 2 * H && Wo == 2 * W && Cin % 32 == 0 && H % 16 == 0 && W % 16 == 0 && a_bytes < 0xFFFF0000ll - 16384 &&
+      b_bytes < 0xFFFFF000ll - 1024 &&
+      // one block per CU: below a block per CU the general kernel's smaller tiles fill the chip better
+      // (ried_conv2d_force_tile(0, 1, 0) lifts this rule: tests reach the kernel with small inputs)
+      ((long long)nimg * (H / 16) * (W / 16) * ceil_div(Cout, Cout <= 32 ? 32 : 64) >= 256 || g_forced_tile[1] == 1)) {
+    const int bm = Cout <= 32 ? 32 : 64;
+    P.tiles_m = ceil_div(Cout, bm);
+    const int ntiles = nimg * (H / 16) * (W / 16);
+    if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = 4 * ntiles; }
+    const dim3 hgrid(P.tiles_m * ntiles);
+    if (bm == 32) hipLaunchKernelGGL(conv_halo_d4_kernel<32>, hgrid, dim3(512), 0, stream, P);
+    else hipLaunchKernelGGL(conv_halo_d4_kernel<64>, hgrid, dim3(512), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
     return RIED_OK;
   }

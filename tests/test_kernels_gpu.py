@@ -206,6 +206,42 @@ def test_conv2d_stride2_data_gradient_halo_kernel(cin, cout, N, H, W):
         close(a, b, 4e-3, what + " vs general kernel")
 
 
+@pytest.mark.parametrize("cin,cout,N,H,W", [(192, 64, 2, 16, 16), (96, 32, 1, 32, 16), (64, 48, 3, 16, 32),
+                                             (32, 128, 1, 16, 16), (384, 128, 1, 16, 16), (96, 24, 2, 16, 16)])
+def test_deconv_4x4_stride2_halo_kernel(cin, cout, N, H, W):
+    """ConvTranspose2d(4, 2, 1) on maps of whole 16x16 tiles takes the four-phase halo kernel (Cin a multiple of
+    32: the half-slab tail is skipped): against torch, and with BatchNorm statistics (plain rows and folded)
+    against the general kernel."""
+    x = r(N, cin, H, W, seed=70)
+    w = r(cin, cout, 4, 4, seed=71, scale=(cin * 4) ** -0.5)                # ConvTranspose2d layout (Cin,Cout,kh,kw)
+    ref = F.conv_transpose2d(x, w, None, 2, 1)
+    wp = pack(w.permute(1, 0, 2, 3))
+    xv = to_view(x)
+    rows = ops.conv2d_stat_rows(N, 2 * H, 2 * W, cin, cout, 4, 4, 2, 2, True)
+    out = {}
+    for name, force in (("halo", (0, 1, 0)), ("general", (-1, 0, 0))):   # (0, 1, 0): the kernel whatever the block count
+        lib.ried_conv2d_force_tile(*force)
+        try:
+            yv = ops.new_view(N, 2 * H, 2 * W, cout)
+            stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
+            ops.conv2d(xv, wp, yv, 4, 4, 2, 2, 1, 1, transposed=True, stats=stats)
+            big = ops.new_view(N, 2 * H, 2 * W, cout + 16, zero=True)       # a channel slice of a wider buffer
+            fold = torch.zeros(ops.bn_fold_rows(), 2, cout, device=DEV)
+            ops.conv2d(xv, wp, big.slice(8, 8 + cout), 4, 4, 2, 2, 1, 1, transposed=True, stats=fold, stats_post=2)
+            out[name] = (from_view(yv), stats.sum(0).cpu(), from_view(big), fold.sum(0).cpu())
+        finally:
+            lib.ried_conv2d_force_tile(0, 0, 0)
+    y, st, yb, fo = out["halo"]
+    close(y, ref, what="y")
+    close(st[0], ref.sum((0, 2, 3)), 3e-3, "sum over phases")
+    close(st[1], (ref * ref).sum((0, 2, 3)), 3e-3, "sum of squares over phases")
+    close(yb[:, 8:8 + cout], ref, what="slice")
+    assert yb[:, :8].abs().max() == 0 and yb[:, 8 + cout:].abs().max() == 0
+    close(fo[1], (ref * ref).sum((0, 2, 3)), 3e-3, "folded sum of squares")
+    for a, b, what in zip(out["halo"], out["general"], ("y", "stats", "slice", "folded stats")):
+        close(a, b, 4e-3, what + " vs general kernel")
+
+
 def test_bn_finalize_folds_many_rows():
     """Thousands of partial rows (512x512 inference) go through the two-step reduction: same statistics."""
     g = torch.Generator().manual_seed(3)
