@@ -215,9 +215,12 @@ long long ried_conv_c1_wgrad_scratch_floats(int Cout);
 int ried_conv_c1_dgrad(const void* dy, long long lddy, const float* w, const float* sigma, float* dx, int nimg, int H,
                        int W, int Cout, float scale, int accumulate, ried_stream_t stream); /* stride 1 */
 
-/* generator out_conv 33->1 on cat(identity, h) (src/rinet.py:70,90): out = w[0]*x + sum_c w[1+c]*h[:,c] */
+/* generator out_conv 33->1 on cat(identity, h) (src/rinet.py:70,90): out = w[0]*x + sum_c w[1+c]*h[:,c].
+ * bn_save [2][32] (mean, invstd) with gamma, beta [32], or all three NULL: with them h is the RAW output of deconv2
+ * and relu(gamma*(h-mean)*invstd+beta) (src/rinet.py:199-205) is applied on the fly - the forward-only path, where
+ * nothing else reads the normalised tensor. */
 int ried_out_conv_fwd(const float* x, const void* h, long long ldh, const float* w, float* out, long long npix,
-                      ried_stream_t stream);
+                      const float* bn_save, const float* gamma, const float* beta, ried_stream_t stream);
 int ried_out_conv_bwd(const float* x, const void* h, long long ldh, const float* w, const float* dout, void* dh,
                       long long lddh, float* dw, long long npix, ried_stream_t stream); /* dw[33] += */
 

@@ -46,12 +46,39 @@ __device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsign
 __device__ __forceinline__ float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
-// 64-lane wave reductions
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane sums without the LDS crossbar (ds_bpermute, which __shfl_xor compiles to): rotations inside the
+// 16-lane rows are DPP modifiers of the add itself, and the two row-combining steps are gfx950's
+// v_permlane16_swap / v_permlane32_swap.  All 64 lanes must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// sum over the four 16-lane rows of a wave, lane by lane (lane l gets v[l%16] + v[l%16+16] + v[l%16+32] + v[l%16+48])
+// (Inline asm: the compiler's builtins for the two swaps return the first result twice in this ROCm release.
+// The s_nop covers the VALU-write -> permlane-read wait states the compiler would otherwise insert itself.)
+__device__ __forceinline__ float rows_sum(float v) {
+  float x = v, y = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y));   // x rows 1,3 <-> y rows 0,2
+  x += y;
+  y = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));   // x lanes 32..63 <-> y lanes 0..31
+  return x + y;
+}
+// sum over the lanes of a 16-lane row that share lane % CLASSES (CLASSES = 1, 2, 4, 8 or 16), in every lane
+template <int CLASSES>
+__device__ __forceinline__ float row_class_sum(float v) {
+  if (CLASSES <= 8) v += dpp_mov<0x128>(v);       // row_ror:8
+  if (CLASSES <= 4) v += dpp_mov<0x124>(v);       // row_ror:4
+  if (CLASSES <= 2) v += dpp_mov<0x122>(v);       // row_ror:2
+  if (CLASSES <= 1) v += dpp_mov<0x121>(v);       // row_ror:1
   return v;
 }
+// sum over the lanes of a wave that share lane % CLASSES, in every lane
+template <int CLASSES>
+__device__ __forceinline__ float class_sum(float v) { return rows_sum(row_class_sum<CLASSES>(v)); }
+
+// 64-lane wave reductions
+__device__ __forceinline__ float wave_sum(float v) { return class_sum<1>(v); }
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -393,10 +393,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        float a = ssum[i][q], b = ssq[i][q];
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-        ssum[i][q] = a; ssq[i][q] = b;
+        ssum[i][q] = row_class_sum<1>(ssum[i][q]);      // over the 16 pixel columns a row of lanes holds
+        ssq[i][q] = row_class_sum<1>(ssq[i][q]);
       }
     }
     if (wn > 0 && (lane & 15) == 0) {
@@ -567,11 +565,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 
     }
     if (E.stats) {
       // lanes with equal lane % CPR hold the same chunk column: butterfly over the others, then one row per wave
+      static_assert(CPR == 4 || CPR == 8 || CPR == 16, "chunks per pixel row");
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-#pragma unroll
-        for (int o = CPR; o < 64; o <<= 1) { s0[q] += __shfl_xor(s0[q], o, 64); s1[q] += __shfl_xor(s1[q], o, 64); }
-      }
+      for (int q = 0; q < 8; ++q) { s0[q] = class_sum<CPR>(s0[q]); s1[q] = class_sum<CPR>(s1[q]); }
       if (lane < CPR) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {

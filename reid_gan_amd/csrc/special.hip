@@ -335,21 +335,36 @@ extern "C" int ried_conv_c1_dgrad(const void* dy, long long lddy, const float* w
 // ---------------------------------------------------------------------------
 // generator output conv: out[p] = w[0]*x[p] + sum_c w[1+c]*h[p][c]   (src/rinet.py:70,90), C = 32
 // ---------------------------------------------------------------------------
+// bn_save / gamma / beta (all or none): h is the raw output of deconv2 and relu(batchnorm(h)) is formed on the fly
+// (src/rinet.py:69,195-205), so that the normalised tensor is never written when nothing else reads it.
 __global__ void out_conv_fwd_kernel(const float* __restrict__ x, const bf16_t* __restrict__ h, long long ldh,
-                                    const float* __restrict__ w, float* __restrict__ out, long long npix) {
+                                    const float* __restrict__ w, float* __restrict__ out, long long npix,
+                                    const float* __restrict__ bn_save, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta) {
   // 4 lanes per pixel, 8 channels each
   long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   long long nthreads = (long long)gridDim.x * blockDim.x;
   long long pend = (npix * 4 + nthreads - 1) / nthreads * nthreads;
+  const int c = (int)(gid & 3) * 8;                    // nthreads is a multiple of 4: fixed per thread
+  float wv[8], a[8], b[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    wv[q] = w[1 + c + q];
+    a[q] = bn_save ? gamma[c + q] * bn_save[32 + c + q] : 1.f;
+    b[q] = bn_save ? beta[c + q] - bn_save[c + q] * a[q] : 0.f;
+  }
   for (long long i = gid; i < pend; i += nthreads) {
     long long p = i >> 2;
-    int c = (int)(i & 3) * 8;
     float acc = 0.f;
     if (p < npix) {
       float f[8];
       unpack8s(*reinterpret_cast<const u32x4*>(h + p * ldh + c), f);
+      if (bn_save) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) acc += f[q] * w[1 + c + q];
+        for (int q = 0; q < 8; ++q) f[q] = fmaxf(f[q] * a[q] + b[q], 0.f);
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc += f[q] * wv[q];
     }
     acc += __shfl_xor(acc, 1, 64);
     acc += __shfl_xor(acc, 2, 64);
@@ -382,12 +397,8 @@ __global__ void out_conv_bwd_kernel(const float* __restrict__ x, const bf16_t* _
   }
   // lanes with equal lane % 4 hold the same channels: butterfly over the other lane bits, one LDS add per wave
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
-#pragma unroll
-    for (int o = 4; o < 64; o <<= 1) s[q] += __shfl_xor(s[q], o, 64);
-  }
-#pragma unroll
-  for (int o = 4; o < 64; o <<= 1) s0 += __shfl_xor(s0, o, 64);
+  for (int q = 0; q < 8; ++q) s[q] = class_sum<4>(s[q]);
+  s0 = class_sum<4>(s0);
   if ((threadIdx.x & 63) < 4) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) atomicAdd(&ldw[1 + c + q], s[q]);
@@ -398,11 +409,14 @@ __global__ void out_conv_bwd_kernel(const float* __restrict__ x, const bf16_t* _
 }
 
 extern "C" int ried_out_conv_fwd(const float* x, const void* h, long long ldh, const float* w, float* out,
-                                 long long npix, hipStream_t stream) {
+                                 long long npix, const float* bn_save, const float* gamma, const float* beta,
+                                 hipStream_t stream) {
   RIED_CHECK_ARG(x && h && w && out && npix > 0 && ldh % 8 == 0 && ldh >= 32 && ((uintptr_t)h % 16) == 0,
                  "ried_out_conv_fwd: bad arguments");
+  RIED_CHECK_ARG((!bn_save && !gamma && !beta) || (bn_save && gamma && beta),
+                 "ried_out_conv_fwd: bn_save, gamma and beta go together");
   hipLaunchKernelGGL(out_conv_fwd_kernel, dim3(ew_grid(npix * 4, SP_THREADS, 2048)), dim3(SP_THREADS), 0, stream, x,
-                     (const bf16_t*)h, ldh, w, out, npix);
+                     (const bf16_t*)h, ldh, w, out, npix, bn_save, gamma, beta);
   RIED_CHECK_LAUNCH("ried_out_conv_fwd");
   return RIED_OK;
 }

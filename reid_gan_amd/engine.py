@@ -416,11 +416,12 @@ class ConvBN:
 
     def __init__(self, ctx: Ctx, prefix: str, cin, cout, k, stride, pad, xin: Slot, out: Slot, deconv=False,
                  accumulate=False, need_dx=True, conv_key=None, bn_key=None, bias=False, act=1, shared=False,
-                 wgrad_out: Optional[torch.Tensor] = None):
+                 wgrad_out: Optional[torch.Tensor] = None, defer_apply=False):
         """bias / act / shared / wgrad_out serve the legacy networks (src/networks.py:466-542): a conv bias in front
         of the BatchNorm (train mode: it only shifts running_mean), the activation code of ops.bn_apply, layers
         applied several times per forward (BatchNorm and bias gradients then add onto the state's), and a
-        private buffer for this use's weight gradient."""
+        private buffer for this use's weight gradient.  defer_apply (forward-only plans): the layer stops at the
+        statistics (`save`); its consumer reads `raw` and applies the normalisation itself."""
         self.ctx, self.prefix, self.lane = ctx, prefix, ctx.build_lane
         conv_key = conv_key or (prefix + (".deconv" if deconv else ".conv"))
         self.bn = bn_key or (prefix + ".bn")
@@ -434,7 +435,9 @@ class ConvBN:
         self.raw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
         self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, cin, c.cout, c.kh, c.kw, c.sh, c.sw, deconv)
-        self.sliced = BN_FOLD and ctx.training and self.raw.npix * cout <= BN_FOLD_MAX_ELEMS
+        self.defer_apply = defer_apply
+        assert not (defer_apply and ctx.grads)
+        self.sliced = BN_FOLD and ctx.training and self.raw.npix * cout <= BN_FOLD_MAX_ELEMS and not defer_apply
         if self.sliced:
             self.stat_rows = min(self.stat_rows, ops.bn_fold_rows())
         ctx.stats(self, "stats", self.stat_rows * 2 * cout, zeroed=self.sliced)
@@ -473,6 +476,8 @@ class ConvBN:
         else:
             c.conv(self.raw, bias=st.p[self.bias_key] if self.bias_key else None)
             ops.bn_eval_stats(st.b[self.bn + ".running_mean"], st.b[self.bn + ".running_var"], c.cout, self.save)
+        if self.defer_apply:
+            return
         ops.bn_apply(self.raw, self.out.v, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
                      relu=self.act, accumulate=self.accumulate)
 
@@ -847,7 +852,9 @@ class Generator:
         body.add(inception_a(ctx, "layer_block_5.0", a8, self.cat1.sub(64, 192), 256, True))
         body.add(ConvBN(ctx, "deconv1", 192, 64, 4, 2, 1, self.cat1, self.cat2.sub(32, 96), deconv=True))
         self.hlast = Slot(ctx.act(N, H, W, 32))
-        body.add(ConvBN(ctx, "deconv2", 96, 32, 4, 2, 1, self.cat2, self.hlast, deconv=True))
+        # forward-only plans: out_conv reads deconv2's raw output and normalises on the fly (hlast stays unwritten)
+        self.last = body.add(ConvBN(ctx, "deconv2", 96, 32, 4, 2, 1, self.cat2, self.hlast, deconv=True,
+                                    defer_apply=not grads))
         self.body = body
         self.tops = {"conv1": self.cat2.sub(0, 32), "conv2": c2, "layer_block_1": a1, "reduce_grid_1": a2,
                      "layer_block_2": a3, "reduce_grid_2": a4, "layer_block_3": a5, "expand_grid_1": a6,
@@ -863,7 +870,11 @@ class Generator:
         self.ctx.begin_forward()
         self.conv1.forward(x)
         self.body.forward()
-        ops.out_conv_fwd(x, self.hlast.v, self.st.p["out_conv.weight"], self.out)
+        if self.last.defer_apply:
+            ops.out_conv_fwd(x, self.last.raw, self.st.p["out_conv.weight"], self.out,
+                             bn=(self.last.save, self.st.p["deconv2.bn.weight"], self.st.p["deconv2.bn.bias"]))
+        else:
+            ops.out_conv_fwd(x, self.hlast.v, self.st.p["out_conv.weight"], self.out)
         return self.out
 
     def backward(self, dout: torch.Tensor):

@@ -423,8 +423,10 @@ def axpy_f32(y: torch.Tensor, x: torch.Tensor, alpha: float):
     lib.ried_axpy_f32(_p(y), _p(x), alpha, y.numel(), _stream())
 
 
-def out_conv_fwd(x: torch.Tensor, h: View, w: torch.Tensor, out: torch.Tensor):
-    lib.ried_out_conv_fwd(_p(x), h.ptr, h.ld, _p(w), _p(out), h.npix, _stream())
+def out_conv_fwd(x: torch.Tensor, h: View, w: torch.Tensor, out: torch.Tensor, bn=None):
+    """bn = (save, gamma, beta): h is the raw conv output and BatchNorm + ReLU are applied on the fly."""
+    save, gamma, beta = bn if bn is not None else (None, None, None)
+    lib.ried_out_conv_fwd(_p(x), h.ptr, h.ld, _p(w), _p(out), h.npix, _p(save), _p(gamma), _p(beta), _stream())
 
 
 def out_conv_bwd(x, h: View, w, dout, dh: View, dw):

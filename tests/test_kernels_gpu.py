@@ -698,6 +698,14 @@ def test_out_conv():
     hv = to_view(h)
     ops.out_conv_fwd(x.to(DEV), hv, w.detach().reshape(33).to(DEV), od)
     close(od.cpu(), out.detach(), 1e-5, "out")
+    # with BatchNorm + ReLU of the raw tensor applied on the fly (the forward-only generator plan)
+    raw = r(N, 32, H, H, seed=29)
+    save = torch.cat([raw.mean((0, 2, 3)), torch.rsqrt(raw.var((0, 2, 3), unbiased=False) + 1e-5)])
+    gamma, beta = 1 + 0.1 * r(32, seed=30), 0.1 * r(32, seed=31)
+    hn = F.relu(F.batch_norm(raw, None, None, gamma, beta, True, 0.1, 1e-5))
+    ops.out_conv_fwd(x.to(DEV), to_view(raw), w.detach().reshape(33).to(DEV), od,
+                     bn=(save.to(DEV), gamma.to(DEV), beta.to(DEV)))
+    close(od.cpu(), F.conv2d(torch.cat([x, hn], 1), w).detach(), 1e-4, "out with fused BatchNorm")
     dh = ops.new_view(N, H, H, 32)
     dw = torch.zeros(33, device=DEV)
     ops.out_conv_bwd(x.to(DEV), hv, w.detach().reshape(33).to(DEV), dout.to(DEV), dh, dw)
