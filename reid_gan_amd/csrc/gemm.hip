@@ -460,13 +460,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
 // (plain, folded, zero-padded); not the BatchNorm hand-off, the attention residual or fp32 outputs.
 // ---------------------------------------------------------------------------
 // SMEM: bytes of LDS the kernel owns; if the whole tile fits it is staged at once, else in two halves.
-template <int BM, int BN, int WN, int SMEM, class RowMap>
+// CARRY (kernels that run several epilogues per block - the output phases of a tile; whole-tile staging only):
+// 1 = the thread's statistics sums are added into carry[16] and nothing is reduced or written, 2 = carry is
+// added in before the block's one reduction.  A thread's chunk column is the same in every call.
+template <int BM, int BN, int WN, int SMEM, class RowMap, int CARRY = 0>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 (&acc)[BM / 32][BN / (16 * WN)],
                                                      int m0, const RowMap& rowmap, int tn, int ntiles_n, int by,
-                                                     void* smem) {
+                                                     void* smem, float* carry = nullptr) {
   constexpr int NT = 128 * WN, NW = 2 * WN, TM = BM / 32, TN = BN / (16 * WN);
   constexpr int HALVES = (BN * (BM + 4) * 4 + NW * 2 * BM * 4 <= SMEM) ? 1 : 2;
   static_assert(BN * (BM / HALVES + 4) * 4 + NW * 2 * (BM / HALVES) * 4 <= SMEM, "staging area");
+  static_assert(CARRY == 0 || HALVES == 1, "carried statistics need whole-tile staging");
   constexpr int HM = BM / HALVES;             // channels per pass: all, or the rows of waves wm = 0, then wm = 1
   constexpr int LDT = HM + 4;                 // floats per staged pixel row (16-byte pad: conflict-free both ways)
   constexpr int CPR = HM / 8;                 // 16-byte output chunks per pixel row
@@ -563,7 +567,14 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 
       *reinterpret_cast<u32x4*>(op) =
           u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
     }
-    if (E.stats) {
+    if (CARRY != 0 && E.stats) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (CARRY == 1) { carry[q] += s0[q]; carry[8 + q] += s1[q]; }
+        else { s0[q] += carry[q]; s1[q] += carry[8 + q]; }
+      }
+    }
+    if (CARRY != 1 && E.stats) {
       // lanes with equal lane % CPR hold the same chunk column: butterfly over the others, then one row per wave
       static_assert(CPR == 4 || CPR == 8 || CPR == 16, "chunks per pixel row");
 #pragma unroll
@@ -1218,11 +1229,20 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams 
     }
   };
   const int Wo = 2 * X.W, HWo = 4 * X.H * X.W;
+  // the four phases' statistics are summed per thread and reduced once: one row per tile
+  float carry[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) carry[q] = 0.f;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const PhaseRowMap rm{(long long)img0 * HWo + (long long)(2 * ty0 + (p >> 1)) * Wo + 2 * tx0 + (p & 1), Wo, HWo,
                          X.nimg - img0};
-    gemm_epilogue_staged<BM, BN, WN, 3 * ABUF + 2 * BBUF>(P, acc[p], m0, rm, tn, ntotal / P.tiles_m, p, smem);
+    if (p < 3)
+      gemm_epilogue_staged<BM, BN, WN, 3 * ABUF + 2 * BBUF, PhaseRowMap, 1>(P, acc[p], m0, rm, tn,
+                                                                            ntotal / P.tiles_m, 0, smem, carry);
+    else
+      gemm_epilogue_staged<BM, BN, WN, 3 * ABUF + 2 * BBUF, PhaseRowMap, 2>(P, acc[p], m0, rm, tn,
+                                                                            ntotal / P.tiles_m, 0, smem, carry);
     __syncthreads();          // the LDS staging area is reused by the next phase
   }
 }
@@ -1394,10 +1414,19 @@ __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P
     }
   };
   const int Wo = 2 * X.W, HWo = 4 * X.H * X.W;
+  // the four phases' statistics are summed per thread and reduced once: one row per tile
+  float carry[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) carry[q] = 0.f;
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const PhaseRowMap rm{(long long)img0 * HWo + (long long)(2 * ty0 + (p >> 1)) * Wo + 2 * tx0 + (p & 1), Wo};
-    gemm_epilogue_staged<BM, BN, WN, NSA * ABUF + 2 * BBUF>(P, acc[p], m0, rm, tn, ntotal / P.tiles_m, p, smem);
+    if (p < 3)
+      gemm_epilogue_staged<BM, BN, WN, NSA * ABUF + 2 * BBUF, PhaseRowMap, 1>(P, acc[p], m0, rm, tn,
+                                                                              ntotal / P.tiles_m, 0, smem, carry);
+    else
+      gemm_epilogue_staged<BM, BN, WN, NSA * ABUF + 2 * BBUF, PhaseRowMap, 2>(P, acc[p], m0, rm, tn,
+                                                                              ntotal / P.tiles_m, 0, smem, carry);
     __syncthreads();          // the LDS staging area is reused by the next phase
   }
 }
@@ -1710,7 +1739,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     const int ts = 16;
     P.tiles_m = ceil_div(Cout, 64);
     const int ntiles = ceil_div(nimg, 256 / (ts * ts)) * (H / ts) * (W / ts);
-    if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = 4 * ntiles; }
+    if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * 256 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
     const dim3 hgrid(P.tiles_m * ntiles);
     hipLaunchKernelGGL(conv_halo_s2t_kernel<16>, hgrid, dim3(512), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
@@ -1726,7 +1755,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     const int bm = Cout <= 32 ? 32 : 64;
     P.tiles_m = ceil_div(Cout, bm);
     const int ntiles = nimg * (H / 16) * (W / 16);
-    if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = 4 * ntiles; }
+    if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * 256 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
     const dim3 hgrid(P.tiles_m * ntiles);
     if (bm == 32) hipLaunchKernelGGL(conv_halo_d4_kernel<32>, hgrid, dim3(512), 0, stream, P);
     else hipLaunchKernelGGL(conv_halo_d4_kernel<64>, hgrid, dim3(512), 0, stream, P);
