@@ -14,6 +14,9 @@
 #define TS 32               // output tile side
 #define HALO 5
 #define TIN (TS + 2 * HALO) // 42
+#define HQS (TS + 1)        // row pitch of the horizontally filtered planes of the forward kernel
+#define TP (TIN + 1)        // row pitch of the input tiles of the forward kernel (43: odd)
+#define TPL (TIN * TP)      // one input plane
 
 struct SsimWindow { float g[11]; };
 
@@ -37,16 +40,23 @@ template <int NIMG>
 __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__ ia, const float* __restrict__ ib,
                                                        const float* __restrict__ ir, int nimg, int H, int W, float c1,
                                                        float c2, int do_clamp, float lo, float hi, SsimWindow win,
-                                                       float* __restrict__ out, float* __restrict__ gmap) {
+                                                       float* __restrict__ out, float* __restrict__ gmap, int tpb) {
   constexpr int NQ = NIMG == 2 ? 5 : 8;
   extern __shared__ float lds[];
-  float* tin = lds;                                // [NIMG][TIN][TIN]
-  float* hq = lds + NIMG * TIN * TIN;              // [NQ][TIN][TS]
-  const int tiles_x = (W + TS - 1) / TS;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, n = blockIdx.y;
-  const int x0 = tx * TS - HALO, y0 = ty * TS - HALO;
+  float* tin = lds;                                // [NIMG][TIN][TP]: odd pitch, conflict-free column walks
+  float* hq = lds + NIMG * TPL;              // [NQ][TIN][HQS]
+  const int tiles_x = (W + TS - 1) / TS, ntiles = tiles_x * ((H + TS - 1) / TS);
+  const int n = blockIdx.y;
   const long long ibase = (long long)n * H * W;
   const float* imgs[3] = {ia, NIMG == 3 ? ib : ir, ir};
+  // A block walks tpb tiles of one image and adds its four sums once at the end: with one block per tile the
+  // float atomics of the 256 tiles of a 512 x 512 image all land on one cache line and serialise - that, not the
+  // filter, was what bounded the kernel on full slices.
+  float s_ssim_a = 0.f, s_mse_a = 0.f, s_ssim_b = 0.f, s_mse_b = 0.f;
+  for (int tile = blockIdx.x * tpb; tile < min(ntiles, (blockIdx.x + 1) * tpb); ++tile) {
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  const int x0 = tx * TS - HALO, y0 = ty * TS - HALO;
+  if (tile != blockIdx.x * tpb) __syncthreads();        // the previous tile's LDS planes have been read
 
   {
     // every global load of the halo tile is issued before the first LDS store, so that the block pays the
@@ -71,86 +81,119 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
     for (int j = 0; j < NL; ++j) {
       int i = threadIdx.x + 256 * j;
       if (i < TIN * TIN) {
+        int yy = i / TIN, xx = i - yy * TIN;
 #pragma unroll
-        for (int k = 0; k < NIMG; ++k) tin[k * TIN * TIN + i] = v[j][k];
+        for (int k = 0; k < NIMG; ++k) tin[k * TPL + yy * TP + xx] = v[j][k];
       }
     }
   }
   __syncthreads();
-  // horizontal pass: TIN rows x TS columns
-  for (int i = threadIdx.x; i < TIN * TS; i += 256) {
-    int yy = i / TS, xx = i - yy * TS;
-    float q[NQ];
+  // Horizontal pass, TIN rows x TS columns: a thread owns 8 consecutive outputs of one row and slides over their
+  // 18 inputs, so that every input (and its products) is read and formed once instead of once per tap.  Lanes
+  // differ in the row: input addresses are 42 floats apart (two-way bank conflicts at worst), output rows are
+  // padded to HQS = 33 floats (conflict-free).
+  for (int task = threadIdx.x; task < TIN * (TS / 8); task += 256) {
+    const int seg = task / TIN, yy = task - seg * TIN;
+    float o[NQ][8];
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) q[k] = 0.f;
+    for (int k = 0; k < NQ; ++k)
 #pragma unroll
-    for (int t = 0; t < 11; ++t) {
-      float g = win.g[t];
+      for (int j = 0; j < 8; ++j) o[k][j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      const int ci = yy * TP + seg * 8 + i;
+      float v[NQ];
       if constexpr (NIMG == 2) {
-        float a = tin[yy * TIN + xx + t], r = tin[TIN * TIN + yy * TIN + xx + t];
-        q[0] += g * a; q[1] += g * r; q[2] += g * (a * a); q[3] += g * (r * r); q[4] += g * (a * r);
+        const float a = tin[ci], r = tin[TPL + ci];
+        v[0] = a; v[1] = r; v[2] = a * a; v[3] = r * r; v[4] = a * r;
       } else {
-        float a = tin[yy * TIN + xx + t], b = tin[TIN * TIN + yy * TIN + xx + t],
-              r = tin[2 * TIN * TIN + yy * TIN + xx + t];
-        q[0] += g * a; q[1] += g * b; q[2] += g * r; q[3] += g * (a * a); q[4] += g * (b * b); q[5] += g * (r * r);
-        q[6] += g * (a * r); q[7] += g * (b * r);
+        const float a = tin[ci], b = tin[TPL + ci], r = tin[2 * TPL + ci];
+        v[0] = a; v[1] = b; v[2] = r; v[3] = a * a; v[4] = b * b; v[5] = r * r; v[6] = a * r; v[7] = b * r;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (i - j >= 0 && i - j <= 10) {             // compile-time: tap i - j of output j, taps in ascending order
+          const float g = win.g[i - j];
+#pragma unroll
+          for (int k = 0; k < NQ; ++k) o[k][j] += g * v[k];
+        }
       }
     }
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) hq[k * TIN * TS + i] = q[k];
+    for (int k = 0; k < NQ; ++k)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) hq[(k * TIN + yy) * HQS + seg * 8 + j] = o[k][j];
   }
   __syncthreads();
-  // vertical pass + quotient: 4 output pixels per thread
-  float s_ssim_a = 0.f, s_mse_a = 0.f, s_ssim_b = 0.f, s_mse_b = 0.f;
-  for (int i = threadIdx.x; i < TS * TS; i += 256) {
-    int yy = i / TS, xx = i - yy * TS;
-    int gy = ty * TS + yy, gx = tx * TS + xx;
-    if (gy >= H || gx >= W) continue;
-    float q[NQ];
+  // Vertical pass + quotient: a thread owns 4 consecutive outputs of one column (lanes: consecutive columns) and
+  // slides over their 14 input rows.
+  {
+    const int xx = threadIdx.x & (TS - 1), ys = (threadIdx.x >> 5) * 4;     // 8 strips of 4 rows
+    float q4[NQ][4];
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) q[k] = 0.f;
+    for (int k = 0; k < NQ; ++k)
 #pragma unroll
-    for (int t = 0; t < 11; ++t) {
-      float g = win.g[t];
+      for (int j = 0; j < 4; ++j) q4[k][j] = 0.f;
 #pragma unroll
-      for (int k = 0; k < NQ; ++k) q[k] += g * hq[k * TIN * TS + (yy + t) * TS + xx];
+    for (int i = 0; i < 14; ++i) {
+      float v[NQ];
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) v[k] = hq[(k * TIN + ys + i) * HQS + xx];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (i - j >= 0 && i - j <= 10) {
+          const float g = win.g[i - j];
+#pragma unroll
+          for (int k = 0; k < NQ; ++k) q4[k][j] += g * v[k];
+        }
+      }
     }
-    if constexpr (NIMG == 2) {
-      float mu1 = q[0], mu2 = q[1];
-      float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-      float s1 = q[2] - mu1s, s2 = q[3] - mu2s, s12 = q[4] - mu12;
-      float A1 = 2.f * mu12 + c1, A2 = 2.f * s12 + c2, B1 = mu1s + mu2s + c1, B2 = s1 + s2 + c2;
-      float ssim = (A1 * A2) / (B1 * B2);
-      s_ssim_a += ssim;
-      float a = tin[(yy + HALO) * TIN + xx + HALO], r = tin[TIN * TIN + (yy + HALO) * TIN + xx + HALO];
-      s_mse_a += (a - r) * (a - r);
-      if (gmap) {
-        float ib1b2 = 1.f / (B1 * B2);
-        long long o = ibase + (long long)gy * W + gx, plane = (long long)nimg * H * W;
-        // d ssim / d mu_a (E fixed), d ssim / d E[aa], d ssim / d E[ar]
-        gmap[o] = (2.f * mu2 * (A2 - A1) - ssim * 2.f * mu1 * (B2 - B1)) * ib1b2;
-        gmap[plane + o] = -ssim / B2;
-        gmap[2 * plane + o] = 2.f * A1 * ib1b2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int yy = ys + j;
+      const int gy = ty * TS + yy, gx = tx * TS + xx;
+      if (gy >= H || gx >= W) continue;
+      float q[NQ];
+#pragma unroll
+      for (int k = 0; k < NQ; ++k) q[k] = q4[k][j];
+      if constexpr (NIMG == 2) {
+        float mu1 = q[0], mu2 = q[1];
+        float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+        float s1 = q[2] - mu1s, s2 = q[3] - mu2s, s12 = q[4] - mu12;
+        float A1 = 2.f * mu12 + c1, A2 = 2.f * s12 + c2, B1 = mu1s + mu2s + c1, B2 = s1 + s2 + c2;
+        float ssim = (A1 * A2) / (B1 * B2);
+        s_ssim_a += ssim;
+        float a = tin[(yy + HALO) * TP + xx + HALO], r = tin[TPL + (yy + HALO) * TP + xx + HALO];
+        s_mse_a += (a - r) * (a - r);
+        if (gmap) {
+          float ib1b2 = 1.f / (B1 * B2);
+          long long o = ibase + (long long)gy * W + gx, plane = (long long)nimg * H * W;
+          // d ssim / d mu_a (E fixed), d ssim / d E[aa], d ssim / d E[ar]
+          gmap[o] = (2.f * mu2 * (A2 - A1) - ssim * 2.f * mu1 * (B2 - B1)) * ib1b2;
+          gmap[plane + o] = -ssim / B2;
+          gmap[2 * plane + o] = 2.f * A1 * ib1b2;
+        }
+      } else {
+        float mua = q[0], mub = q[1], mur = q[2];
+        float murs = mur * mur, sr = q[5] - murs;
+        {
+          float m1s = mua * mua, m12 = mua * mur;
+          float s1 = q[3] - m1s, s12 = q[6] - m12;
+          s_ssim_a += ((2.f * m12 + c1) * (2.f * s12 + c2)) / ((m1s + murs + c1) * (s1 + sr + c2));
+        }
+        {
+          float m1s = mub * mub, m12 = mub * mur;
+          float s1 = q[4] - m1s, s12 = q[7] - m12;
+          s_ssim_b += ((2.f * m12 + c1) * (2.f * s12 + c2)) / ((m1s + murs + c1) * (s1 + sr + c2));
+        }
+        int ci = (yy + HALO) * TP + xx + HALO;
+        float a = tin[ci], b = tin[TPL + ci], r = tin[2 * TPL + ci];
+        s_mse_a += (a - r) * (a - r);
+        s_mse_b += (b - r) * (b - r);
       }
-    } else {
-      float mua = q[0], mub = q[1], mur = q[2];
-      float murs = mur * mur, sr = q[5] - murs;
-      {
-        float m1s = mua * mua, m12 = mua * mur;
-        float s1 = q[3] - m1s, s12 = q[6] - m12;
-        s_ssim_a += ((2.f * m12 + c1) * (2.f * s12 + c2)) / ((m1s + murs + c1) * (s1 + sr + c2));
-      }
-      {
-        float m1s = mub * mub, m12 = mub * mur;
-        float s1 = q[4] - m1s, s12 = q[7] - m12;
-        s_ssim_b += ((2.f * m12 + c1) * (2.f * s12 + c2)) / ((m1s + murs + c1) * (s1 + sr + c2));
-      }
-      int ci = (yy + HALO) * TIN + xx + HALO;
-      float a = tin[ci], b = tin[TIN * TIN + ci], r = tin[2 * TIN * TIN + ci];
-      s_mse_a += (a - r) * (a - r);
-      s_mse_b += (b - r) * (b - r);
     }
   }
+  }     // tiles of this block
   __shared__ float sh4[4];
   float t0 = block_sum_256(s_ssim_a, sh4);
   float t1 = block_sum_256(s_mse_a, sh4);
@@ -224,15 +267,25 @@ extern "C" int ried_ssim_fwd(const float* a, const float* b, const float* ref, i
   RIED_CHECK_ARG(!(b && gmap), "ried_ssim_fwd: gradient maps need the two-image form");
   static const SsimWindow win = make_window();
   int tiles = ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
-  dim3 grid(tiles, nimg);
+  // tiles per block: about four blocks per CU in all, at most 16 tiles each
+  int tpb = (int)(((long long)tiles * nimg + 1023) / 1024);
+  tpb = tpb < 1 ? 1 : tpb > 16 ? 16 : tpb;
+  dim3 grid((tiles + tpb - 1) / tpb, nimg);
   if (b) {
-    size_t sh = (3 * TIN * TIN + 8 * TIN * TS) * sizeof(float);
+    size_t sh = (3 * TPL + 8 * TIN * HQS) * sizeof(float);          // 66 KB: above the 64 KB default limit
+    static int raised = 0;
+    if (!raised) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ssim_fwd_kernel<3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      RIED_CHECK_ARG(e == hipSuccess, "ried_ssim_fwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+      raised = 1;
+    }
     hipLaunchKernelGGL(ssim_fwd_kernel<3>, grid, dim3(256), sh, stream, a, b, ref, nimg, H, W, c1, c2, do_clamp, lo,
-                       hi, win, sums, (float*)nullptr);
+                       hi, win, sums, (float*)nullptr, tpb);
   } else {
-    size_t sh = (2 * TIN * TIN + 5 * TIN * TS) * sizeof(float);
+    size_t sh = (2 * TPL + 5 * TIN * HQS) * sizeof(float);
     hipLaunchKernelGGL(ssim_fwd_kernel<2>, grid, dim3(256), sh, stream, a, (const float*)nullptr, ref, nimg, H, W, c1,
-                       c2, do_clamp, lo, hi, win, sums, gmap);
+                       c2, do_clamp, lo, hi, win, sums, gmap, tpb);
   }
   RIED_CHECK_LAUNCH("ried_ssim_fwd");
   return RIED_OK;
