@@ -24,7 +24,6 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from .dp import allreduce_mean
 from .engine import Discriminator, Generator, State, Vgg, side_stream, N_LANES
 
 F32 = torch.float32
@@ -47,6 +46,9 @@ class TrainStep:
         if process_group is not None:
             import torch.distributed as dist
             self.world = dist.get_world_size(process_group)
+        # With a process group the step is split into graph segments at the collectives and the all-reduces are
+        # really issued, also for a group of one rank (which is how the path is exercised on a single GPU).
+        self.segmented = process_group is not None
         self.gs, self.ds = State(g_sd, device), State(d_sd, device)
         B = batch
         self.G = Generator(self.gs, B, H, W, grads=True, training=True, device=device)
@@ -69,7 +71,11 @@ class TrainStep:
 
     # ------------------------------------------------------------------ collectives
     def _allreduce_mean(self, t: torch.Tensor):
-        allreduce_mean(t, self.pg, self.world)
+        if self.pg is not None:
+            import torch.distributed as dist
+            dist.all_reduce(t, group=self.pg)
+            if self.world > 1:
+                t.mul_(1.0 / self.world)
 
     # ------------------------------------------------------------------ the step
     # The step is written as a generator that yields the tensors to average across ranks.  With one rank the
@@ -157,7 +163,7 @@ class TrainStep:
             self.v_in[B:].copy_(self.y)
             self.V.forward(self.v_in, B, 2 * B)
         pred = self.G.forward(self.x)
-        if self.world > 1:           # a side stream may not stay open across a collective (graph segment boundary)
+        if self.segmented:           # a side stream may not stay open across a collective (graph segment boundary)
             self._join(self._vgg_side)
             self._vgg_side = None
         self.d_in[:B].copy_(self.y)
@@ -207,7 +213,7 @@ class TrainStep:
                     except StopIteration:
                         done, t = True, None
                         break
-                    if self.world > 1:
+                    if self.segmented:
                         break                 # close this graph at the collective
             pool = g.pool()
             graphs.append((g, t))
@@ -232,8 +238,7 @@ class TrainStep:
     def losses(self) -> Dict[str, float]:
         """Host read of the last step's scalars (synchronises)."""
         s = self.sc.clone()
-        if self.world > 1:
-            self._allreduce_mean(s)
+        self._allreduce_mean(s)
         s = s.cpu()
         return {"dloss1": s[SC_DLOSS1].item(), "dloss2": s[SC_DLOSS2].item(), "gloss": s[SC_GLOSS].item(),
                 "vgg": s[SC_VGG].item(), "dssim": s[SC_DSSIM].item(), "gen": s[SC_GEN].item(),

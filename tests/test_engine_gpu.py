@@ -310,19 +310,46 @@ def test_segmented_graphs_equal_single_graph(monkeypatch):
     monkeypatch.setattr(engine, "BN_FOLD", False)        # fixed-order reductions: the two runs must agree closely
     one = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
     seg = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
-    seg.world = 2
-    seg._allreduce_mean = lambda t: None
+    seg.segmented = True
     for ts in (one, seg):
         ts.step(x.to(DEV), y.to(DEV))
         ts.step()
     torch.cuda.synchronize()
     assert len(seg.graphs) > 3 and len(one.graphs) == 1
-    seg.world = 1                     # losses() would all-reduce
     a, b = one.losses(), seg.losses()
     for k in a:
         assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
     assert torch.allclose(one.gs.flat, seg.gs.flat, rtol=0, atol=3e-4)
     assert torch.allclose(one.ds.flat, seg.ds.flat, rtol=0, atol=1.2e-3)
+
+
+def test_train_step_through_a_one_rank_rccl_group(monkeypatch):
+    """The data-parallel form of the step on one GPU: a process group of one rank (backend nccl = RCCL), so the
+    graph segments are replayed with real all-reduces issued between them on the same stream.  The mean over one
+    rank is the identity: losses and weights must equal the single-graph step."""
+    import socket
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    B, H = 4, 64
+    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
+    x, y = synth_batch(B, H, seed=98)
+    monkeypatch.setattr(engine, "BN_FOLD", False)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        one = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+        par = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True, process_group=dist.group.WORLD)
+        for ts in (one, par):
+            ts.step(x.to(DEV), y.to(DEV))
+            ts.step()
+        torch.cuda.synchronize()
+        assert par.world == 1 and len(par.graphs) > 3 and len(one.graphs) == 1
+        a, b = one.losses(), par.losses()
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
+        assert torch.allclose(one.gs.flat, par.gs.flat, rtol=0, atol=3e-4)
+        assert torch.allclose(one.ds.flat, par.ds.flat, rtol=0, atol=1.2e-3)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_inference_metrics_vs_oracle():
