@@ -217,6 +217,42 @@ def loader_bench(batch=128, patch=64, patch_n=16, nslices=64, size=512, iters=50
     return out
 
 
+def vgg_bench(batch=256, size=256, iters=4):
+    """The perceptual-loss-heavy configuration: VGG16 taps of `batch` prediction and `batch` target patches of
+    size x size, the five-tap MSE and its gradient w.r.t. the prediction (src/loss.py:179-189 and its autograd).
+    Needed work per patch: two forwards + one data-gradient pass = 3 x 305,856 MACs per input pixel."""
+    from reid_gan_amd.engine import Vgg
+    from reid_gan_amd.synth import synth_batch, synth_vgg
+    V = Vgg(synth_vgg(), batch, size, size)
+    nb = min(batch, 8)                              # the synthetic images repeat: generating 512 of them is host time
+    p, y = synth_batch(nb, size, seed=1234)
+    reps = (batch + nb - 1) // nb
+    imgs = torch.cat([p.repeat(reps, 1, 1, 1)[:batch], y.repeat(reps, 1, 1, 1)[:batch]], 0).cuda()
+    loss = torch.zeros(1, device="cuda")
+    dpred = torch.zeros(batch, 1, size, size, device="cuda")
+
+    def step():
+        V.forward(imgs, batch, 2 * batch)
+        V.ctx.zero_backward()
+        V.forward_pred_fused(imgs, 0.3)
+        V.loss_from_rows(loss)
+        V.backward(dpred)
+    step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    flops = 2.0 * 3 * 305856 * size * size * batch
+    return {"metric": "patches/sec through the VGG16 perceptual loss (two forwards + data gradient)",
+            "value": batch / (ms * 1e-3), "unit": "patches/s", "ms_per_step": ms, "batch": batch, "patch": size,
+            "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
+                         "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / PEAK_MFMA_BF16}}
+
+
 def prep_bench(nslices=208, size=512, iters=20, cpu=True):
     """get_pixels_hu (src/prep.py:46-59) on one series resident in HBM: 2 B read + 2 B written per pixel."""
     import numpy as np
@@ -406,6 +442,7 @@ def main():
             out["loader"] = loader_bench(cpu=not args.no_cpu_baseline)
             out["legacy"] = legacy_bench(cpu=not args.no_cpu_baseline)
             out["prep"] = prep_bench(cpu=not args.no_cpu_baseline)
+            out["vgg256"] = vgg_bench()
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))

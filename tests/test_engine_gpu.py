@@ -191,9 +191,9 @@ def test_discriminator_forward_backward_vs_oracle_and_golden(golden_dir):
               "second forward vs golden (fp32 reference)", mx=1.0, mean=5e-2)
 
 
-def test_vgg_taps_and_perceptual_gradient():
+@pytest.mark.parametrize("B,H", [(2, 32), (1, 256)])      # 256 x 256: the patch size of the perceptual-heavy config
+def test_vgg_taps_and_perceptual_gradient(B, H):
     vgg = synth_vgg()
-    B, H = 2, 32
     pred, y = synth_batch(B, H, seed=41)
     pr = pred.clone().requires_grad_(True)
     with emu():
