@@ -109,17 +109,20 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const long long* __restr
   const long long inner = (long long)R * S * C, total = J[3] * inner;
   const float inv = sigma ? 1.f / sigma[0] : 1.f;
   long long i0 = (long long)blockmap[2 * blockIdx.x + 1] * JOB_CHUNK;
-  if (total < (1ll << 31) && !J[12] && (C & 1) == 0 && (pitch & 1) == 0) {
-    // the common case: 32-bit index arithmetic, two channels per thread, one 4-byte store (8 passes of 256 pairs)
+  if (total < (1ll << 30) && !J[12] && (C & 1) == 0 && (pitch & 1) == 0) {
+    // the common case: 32-bit index arithmetic (divisions by float reciprocal + one correction step), two
+    // channels per thread, one 4-byte store (4 passes of 256 pairs)
     const int tot = (int)total, inn = (int)inner, j0 = (int)i0;
+    const float invC = 1.f / (float)C, invS = 1.f / (float)S, invR = 1.f / (float)R;
     bf16_t* dst = (bf16_t*)J[1];
 #pragma unroll
     for (int u = 0; u < JOB_CHUNK / 512; ++u) {
       const int i = j0 + (u * 256 + threadIdx.x) * 2;
       if (i >= tot) break;
-      const int t = i / C, c = i - t * C;
-      const int t2 = t / S, s_ = t - t2 * S;
-      const int n = t2 / R, r = t2 - n * R;
+      int c, s_, r;
+      const int t = fast_div(i, C, invC, c);
+      const int t2 = fast_div(t, S, invS, s_);
+      const int n = fast_div(t2, R, invR, r);
       const float* q = src + (long long)n * sn + r * sr + s_ * ss + c * sc;
       const float v0 = q[0] * inv, v1 = q[sc] * inv;
       *reinterpret_cast<unsigned*>(dst + (long long)n * pitch + (i - n * inn)) = pack2bf(v0, v1);
