@@ -3,7 +3,7 @@
  * The reference (kevinmfreire/REID-GAN) is pure Python on torch.nn; it has no FFI of its own.
  * Each entry point below therefore replaces the stock torch op(s) a reference line invokes; the
  * citation names that line (paths relative to the reference repo).  A binding is a plain
- * ctypes / cffi declaration of these prototypes.
+ * ctypes / cffi declaration of these prototypes (reid_gan_amd/_lib.py generates one from this file).
  *
  * Conventions
  *  - Every function returns 0 on success, non-zero on failure; ried_last_error() then holds a
