@@ -143,7 +143,7 @@ def cpu_baseline(budget_s=20.0):
                       f"({dt:.1f} s)"}
 
 
-def infer_bench(steps=5, warmup=2, batch=32, size=512):
+def infer_bench(steps=5, warmup=2, batch=32, size=512, slice_mode=False):
     from reid_gan_amd.synth import synth_batch
     from reid_gan_amd.train_step import InferenceEngine
     g, _, _ = synth_states()
@@ -171,7 +171,31 @@ def infer_bench(steps=5, warmup=2, batch=32, size=512):
     torch.cuda.synchronize()
     mms = m0.elapsed_time(m1) / 20
     bytes_alg = batch * size * size * 12.0
+    # the reference's loop as written (batch-1 loader: BatchNorm statistics per slice), batched by running the
+    # slices' batch-1 plans side by side
+    per_slice = None
+    if slice_mode:
+        from reid_gan_amd.train_step import SliceInference
+        del eng
+        torch.cuda.empty_cache()
+        se = SliceInference(g, batch, size, size)
+        for _ in range(2):
+            se.run(x, y)
+        torch.cuda.synchronize()
+        s0, s1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s0.record()
+        for _ in range(steps):
+            se.run(x, y)
+        s1.record()
+        torch.cuda.synchronize()
+        sms = s0.elapsed_time(s1) / steps
+        per_slice = {"value": batch / (sms * 1e-3), "unit": "slices/s", "ms_per_batch": sms, "lanes": se.lanes,
+                     "note": "BatchNorm statistics of each slice alone (src/test.py:107-131 runs a batch-1 loader); "
+                             "'value' above is the generator applied to the whole batch"}
+        del se
+        torch.cuda.empty_cache()
     return {"metric": "512x512 slices/sec (generator inference + SSIM/PSNR/RMSE)", "value": batch / (ms * 1e-3),
+            "per_slice_statistics": per_slice,
             "unit": "slices/s", "ms_per_batch": ms, "batch": batch,
             "mfma_frac": batch / (ms * 1e-3) * 34.67e9 / PEAK_MFMA_BF16,
             "metrics_kernel": {"bound": "hbm", "ms": mms, "achieved": bytes_alg / (mms * 1e-3) / 1e9,
@@ -438,7 +462,7 @@ def main():
         if world == 1 and not args.no_infer:
             del ts
             torch.cuda.empty_cache()
-            out["infer"] = infer_bench()
+            out["infer"] = infer_bench(slice_mode=True)
             out["loader"] = loader_bench(cpu=not args.no_cpu_baseline)
             out["legacy"] = legacy_bench(cpu=not args.no_cpu_baseline)
             out["prep"] = prep_bench(cpu=not args.no_cpu_baseline)

@@ -253,6 +253,8 @@ N_LANES = 4
 # (or RIED_DETERMINISTIC=1) keeps every reduction in a fixed order: runs are then bit-reproducible.
 BN_FOLD = not os.environ.get("RIED_DETERMINISTIC")
 BN_FOLD_MAX_ELEMS = int(os.environ.get("RIED_BN_FOLD_MAX_ELEMS", 4 << 20))
+PAR_BRANCHES = True      # False: Par runs its branches one after another on the caller's stream (whole plans are
+                         # then the unit of concurrency: see train_step.SliceInference)
 _side_streams: List["torch.cuda.Stream"] = []
 
 
@@ -635,7 +637,7 @@ class Par:
         self.ctx, self.branches = ctx, branches
 
     def _run(self, fn_name: str):
-        if os.environ.get("RIED_SERIAL_BRANCHES"):          # debugging aid: one stream
+        if os.environ.get("RIED_SERIAL_BRANCHES") or not PAR_BRANCHES:     # one stream (debugging aid; replica lanes)
             for b in self.branches:
                 getattr(b, fn_name)()
             return
@@ -829,7 +831,9 @@ def inception_d(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
 class Generator:
     """RIGAN (src/rinet.py:34-92) for a fixed (N, H, W).  x and the output are fp32 (N,1,H,W)."""
 
-    def __init__(self, state: State, N: int, H: int, W: int, grads=True, training=True, device="cuda"):
+    def __init__(self, state: State, N: int, H: int, W: int, grads=True, training=True, device="cuda",
+                 out: Optional[torch.Tensor] = None):
+        """out: where the (N,1,H,W) fp32 result goes (default: an own buffer)."""
         assert H % 16 == 0 and W % 16 == 0, "RIGAN needs H, W divisible by 16 (skip connections must line up)"
         self.st = state
         self.ctx = ctx = Ctx(state, device, grads, training)
@@ -860,7 +864,8 @@ class Generator:
                      "layer_block_2": a3, "reduce_grid_2": a4, "layer_block_3": a5, "expand_grid_1": a6,
                      "layer_block_4": a7, "expand_grid_2": a8, "layer_block_5": self.cat1.sub(64, 192),
                      "deconv1": self.cat2.sub(32, 96), "deconv2": self.hlast}
-        self.out = torch.empty(N, 1, H, W, dtype=F32, device=device)
+        self.out = torch.empty(N, 1, H, W, dtype=F32, device=device) if out is None else out
+        assert self.out.shape == (N, 1, H, W) and self.out.dtype == F32 and self.out.is_contiguous()
         ctx.finalize()
         self.x = None
 

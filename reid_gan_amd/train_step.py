@@ -32,6 +32,17 @@ F32 = torch.float32
 SC_MEAN_POS, SC_MEAN_NEG, SC_DLOSS, SC_CPOS, SC_CNEG, SC_VGG, SC_SSIM, SC_DSSIM, SC_GEN, SC_GLOSS = range(10)
 SC_DLOSS1, SC_DLOSS2 = 10, 11
 
+# Captured graphs are kept until the process ends.  On this ROCm release (7.2), destroying a graph captured across
+# many streams while a graph captured after it is still alive makes the first replay of the next capture crash in
+# the runtime (host segmentation fault in hipGraphLaunch); a graph that is never destroyed costs a few host
+# objects (nothing is allocated during these captures, so the graphs' private memory pools are empty).
+_RETAINED_GRAPHS = []
+
+
+def _retain(graph):
+    _RETAINED_GRAPHS.append(graph)
+    return graph
+
 
 class TrainStep:
     def __init__(self, g_sd: Dict[str, torch.Tensor], d_sd: Dict[str, torch.Tensor], vgg: Dict[str, torch.Tensor],
@@ -204,7 +215,7 @@ class TrainStep:
         pool = None
         done = False
         while not done:
-            g = torch.cuda.CUDAGraph()
+            g = _retain(torch.cuda.CUDAGraph())
             with torch.cuda.graph(g, pool=pool):
                 t = None
                 while True:
@@ -282,7 +293,7 @@ class InferenceEngine:
                 torch.cuda.synchronize()
                 for k, v in snap.items():
                     self.gs.b[k].copy_(v)
-                self.graph = torch.cuda.CUDAGraph()
+                self.graph = _retain(torch.cuda.CUDAGraph())
                 with torch.cuda.graph(self.graph):
                     self._body()
             self.graph.replay()
@@ -299,3 +310,66 @@ class InferenceEngine:
             p = (10 * math.log10(dr * dr / s[i, 3].item()), s[i, 2].item(), math.sqrt(s[i, 3].item()))
             out.append((o, p))
         return out
+
+
+class SliceInference(InferenceEngine):
+    """The reference's evaluation loop as it is written - a batch-1 loader, so train-mode BatchNorm normalises
+    every slice with that slice's own statistics (src/test.py:107-131) - at batch throughput.  Each slice of the
+    batch goes through its own batch-1 generator plan; `lanes` plans run side by side on parallel streams (a
+    single batch-1 pass is some 360 short dependent launches that leave most of the chip idle), all inside one
+    HIP graph, and one metrics launch covers the batch.  InferenceEngine, in contrast, is the generator applied
+    to the whole batch at once (statistics over the batch).  Every plan keeps its own copy of the BatchNorm
+    running statistics (the loop's outputs do not depend on them)."""
+
+    def __init__(self, g_sd: Dict[str, torch.Tensor], batch: int, H: int, W: int, device="cuda", lanes: int = 16,
+                 lo=-160.0, hi=240.0, use_graph=True):
+        from . import engine
+        ops.require_gpu()
+        self.B, self.H, self.W, self.lo, self.hi = batch, H, W, lo, hi
+        self.lanes = max(1, min(lanes, batch))
+        self.sums = torch.zeros(batch, 4, dtype=F32, device=device)
+        self.x = torch.zeros(batch, 1, H, W, dtype=F32, device=device)
+        self.y = torch.zeros(batch, 1, H, W, dtype=F32, device=device)
+        self.pred = torch.empty(batch, 1, H, W, dtype=F32, device=device)
+        self.states = [State(g_sd, device) for _ in range(batch)]
+        self.gs = self.states[0]
+        self.plans = [Generator(self.states[i], 1, H, W, grads=False, training=True, device=device,
+                                out=self.pred[i:i + 1]) for i in range(batch)]
+        self.G = self.plans[0]
+        self._engine = engine
+        self.use_graph, self.graph = use_graph, None
+
+    def _body(self):
+        eng = self._engine
+        main = torch.cuda.current_stream()
+        saved, eng.PAR_BRANCHES = eng.PAR_BRANCHES, False      # the plans, not their Inception branches, run in parallel
+        try:
+            for lane in range(self.lanes):
+                s = side_stream(N_LANES + 2 + lane)
+                s.wait_stream(main)
+                with torch.cuda.stream(s):
+                    for i in range(lane, self.B, self.lanes):
+                        self.plans[i].forward(self.x[i:i + 1])
+            for lane in range(self.lanes):
+                main.wait_stream(side_stream(N_LANES + 2 + lane))
+        finally:
+            eng.PAR_BRANCHES = saved
+        dr = self.hi - self.lo
+        self.sums.zero_()
+        ops.ssim_fwd(self.x, self.pred, self.y, (0.01 * dr) ** 2, (0.03 * dr) ** 2, self.sums, clamp=(self.lo, self.hi))
+
+    def run(self, x: torch.Tensor, y: torch.Tensor):
+        """Returns (pred, sums) as InferenceEngine.run does."""
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        if not self.use_graph:
+            self._body()
+        else:
+            if self.graph is None:
+                self._body()                       # loads every kernel before the capture
+                torch.cuda.synchronize()
+                self.graph = _retain(torch.cuda.CUDAGraph())
+                with torch.cuda.graph(self.graph):
+                    self._body()
+            self.graph.replay()
+        return self.pred, self.sums

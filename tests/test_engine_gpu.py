@@ -352,6 +352,36 @@ def test_train_step_through_a_one_rank_rccl_group(monkeypatch):
         dist.destroy_process_group()
 
 
+def test_slice_inference_is_the_batch_one_loop():
+    """SliceInference: every slice normalised with its own statistics, as the reference's batch-1 evaluation loop
+    does - against the batch-1 engine slice by slice, against the oracle's forward of each slice alone, and unlike
+    the whole-batch engine."""
+    from reid_gan_amd.train_step import SliceInference
+    sd = g_state()
+    B, H = 5, 64
+    x, y = synth_batch(B, H, seed=55)
+    x[1] = x[1] * 0.25 - 600.0                  # slices with different statistics: batch and slice normalisation differ
+    x[3] = x[3] * 1.5 + 300.0
+    sl = SliceInference(sd, B, H, H, lanes=3)
+    pred, sums = sl.run(x.to(DEV), y.to(DEV))
+    pred, got = pred.cpu().clone(), sl.measures(sums)
+    one = InferenceEngine(sd, 1, H, H)
+    for i in range(B):
+        p1, s1 = one.run(x[i:i + 1].to(DEV), y[i:i + 1].to(DEV))
+        act_close(pred[i:i + 1], p1.cpu(), f"slice {i} vs the batch-1 engine", mx=5e-3, mean=5e-4)
+        m1 = one.measures(s1)[0]
+        for a, b in zip(got[i][1], m1[1]):
+            assert abs(a - b) <= 2e-3 * abs(b) + 1e-5, (i, got[i], m1)
+        with torch.no_grad():
+            ref = O.rigan_forward(O.Params({k: v.clone() for k, v in sd.items()}), x[i:i + 1], True)
+        act_close(pred[i:i + 1], ref, f"slice {i} vs the oracle's batch-1 forward", mx=2e-2, mean=5e-3)
+    whole, _ = InferenceEngine(sd, B, H, H).run(x.to(DEV), y.to(DEV))
+    assert (whole.cpu() - pred).abs().mean() > 10 * (pred[0:1] - one.run(x[0:1].to(DEV), y[0:1].to(DEV))[0].cpu()).abs().mean()
+    # replays reuse the plans
+    pred2, _ = sl.run(x.to(DEV), y.to(DEV))
+    act_close(pred2.cpu(), pred, "second run", mx=5e-3, mean=5e-4)
+
+
 def test_inference_metrics_vs_oracle():
     sd = g_state()
     B, H = 2, 128
