@@ -175,10 +175,9 @@ def infer_bench(steps=5, warmup=2, batch=32, size=512, slice_mode=False):
     # slices' batch-1 plans side by side
     per_slice = None
     if slice_mode:
-        from reid_gan_amd.train_step import SliceInference
         del eng
         torch.cuda.empty_cache()
-        se = SliceInference(g, batch, size, size)
+        se = InferenceEngine(g, batch, size, size, per_slice_stats=True)
         for _ in range(2):
             se.run(x, y)
         torch.cuda.synchronize()
@@ -189,9 +188,9 @@ def infer_bench(steps=5, warmup=2, batch=32, size=512, slice_mode=False):
         s1.record()
         torch.cuda.synchronize()
         sms = s0.elapsed_time(s1) / steps
-        per_slice = {"value": batch / (sms * 1e-3), "unit": "slices/s", "ms_per_batch": sms, "lanes": se.lanes,
-                     "note": "BatchNorm statistics of each slice alone (src/test.py:107-131 runs a batch-1 loader); "
-                             "'value' above is the generator applied to the whole batch"}
+        per_slice = {"value": batch / (sms * 1e-3), "unit": "slices/s", "ms_per_batch": sms,
+                     "note": "BatchNorm statistics of each slice alone, inside the batched kernels (src/test.py:107-131 "
+                             "runs a batch-1 loader); 'value' above is the generator applied to the whole batch"}
         del se
         torch.cuda.empty_cache()
     return {"metric": "512x512 slices/sec (generator inference + SSIM/PSNR/RMSE)", "value": batch / (ms * 1e-3),

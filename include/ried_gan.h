@@ -45,7 +45,11 @@ int ried_device_cus(void);
  *   stats_post = 1: the stats rows hold column sums of the FINAL values (sum in [r][0][c]) - the bias gradient of
  *   the layer below (src/rinet.py:137) - instead of the raw results.
  *   stats_post = 2: the raw sums are ADDED (float atomics) into row (tile mod ried_bn_fold_rows()) of a buffer the
- *   caller zeroed, so that min(rows, ried_bn_fold_rows()) rows hold the totals: the form ried_bn_apply_train reads. */
+ *   caller zeroed, so that min(rows, ried_bn_fold_rows()) rows hold the totals: the form ried_bn_apply_train reads.
+ *   stats_post = 3: the raw sums are ADDED into row (image index) of a zeroed [nimg][2][Cout] buffer: statistics per
+ *   image, for the evaluation loop of src/test.py:107-131, whose batch-1 loader makes train-mode BatchNorm normalise
+ *   every slice on its own (follow with ried_bn_finalize_images / ried_bn_apply_images).  Maps must consist of whole
+ *   pixel tiles (any map of at least 16 x 16 with sides divisible by 16 does). */
 int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W, int Cin,
                 int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
                 const float* bias, int act, float* stats, int accumulate, int out_f32, float* y2, long long ldy2,
@@ -146,6 +150,16 @@ int ried_bn_apply_train(const void* x, long long ldx, void* y, long long ldy, lo
                         const float* stats, int nrows, float eps, float momentum, float* save, float* running_mean,
                         float* running_var, long long* num_batches_tracked, const float* gamma, const float* beta,
                         int relu, int accumulate, ried_stream_t stream);
+/* Per-image train-mode statistics: the evaluation loop of src/test.py:107-131 feeds one slice at a time, so its
+ * BatchNorm layers normalise every slice on its own.  stats: [nimg * rows_per_img][2][C] partial rows, the rows of an
+ * image consecutive (rows_per_img = 1 after ried_conv2d with stats_post = 3); count = pixels per image;
+ * save [nimg][2][C] = (mean, 1/sqrt(var + eps)).  ried_bn_apply_images = ried_bn_apply with that per-image save on
+ * views of nimg images of npix_per_img pixels.  Running statistics are not touched. */
+int ried_bn_finalize_images(const float* stats, int rows_per_img, int nimg, int C, long long count, float eps,
+                            float* save, ried_stream_t stream);
+int ried_bn_apply_images(const void* x, long long ldx, void* y, long long ldy, long long npix_per_img, int nimg, int C,
+                         const float* save, const float* gamma, const float* beta, int relu, int accumulate,
+                         ried_stream_t stream);
 /* dx = d(loss)/d(conv output) from dy = d(loss)/d(bn+relu output); scratch: fp32
  * [ried_bn_backward_scratch_floats(C)] (need not be zeroed); dgamma/dbeta may be NULL; counter: NULL, or one
  * zero-initialised unsigned per layer (left at zero) - the last block of the reduction then finishes the sums. */
@@ -220,7 +234,8 @@ int ried_conv_c1_dgrad(const void* dy, long long lddy, const float* w, const flo
  * and relu(gamma*(h-mean)*invstd+beta) (src/rinet.py:199-205) is applied on the fly - the forward-only path, where
  * nothing else reads the normalised tensor. */
 int ried_out_conv_fwd(const float* x, const void* h, long long ldh, const float* w, float* out, long long npix,
-                      const float* bn_save, const float* gamma, const float* beta, ried_stream_t stream);
+                      const float* bn_save, const float* gamma, const float* beta, int bn_images,
+                      ried_stream_t stream); /* bn_images > 1: bn_save is [bn_images][2][32], one set per image */
 int ried_out_conv_bwd(const float* x, const void* h, long long ldh, const float* w, const float* dout, void* dh,
                       long long lddh, float* dw, long long npix, ried_stream_t stream); /* dw[33] += */
 

@@ -356,12 +356,16 @@ __device__ __forceinline__ float bn_act_grad(float v, float g, int act) {
 }
 
 // y = act(gamma*(x-mean)*invstd + beta) [+ y]
+// gridDim.y > 1: one statistics set per image (save [gridDim.y][2][C], npix pixels each)
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
     const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy, long long npix, int C,
     const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
     int accumulate) {
   ChanWalk w(C);
   if (!w.active) return;
+  x += (long long)blockIdx.y * npix * ldx;
+  y += (long long)blockIdx.y * npix * ldy;
+  save += (long long)blockIdx.y * 2 * C;
   const int c = w.c;
   float a[8], b[8];
 #pragma unroll
@@ -392,6 +396,44 @@ extern "C" int ried_bn_apply(const void* x, long long ldx, void* y, long long ld
   hipLaunchKernelGGL(bn_apply_kernel, dim3(chan_grid(npix, C, 2, 8192)), dim3(EW_THREADS), 0, stream,
                      (const bf16_t*)x, ldx, (bf16_t*)y, ldy, npix, C, save, gamma, beta, relu, accumulate);
   RIED_CHECK_LAUNCH("ried_bn_apply");
+  return RIED_OK;
+}
+
+// Per-image train-mode statistics (the batch-1 evaluation loop of src/test.py:107-131 on a batch).
+// stats: [nimg * rows_per_img][2][C] partial (sum, sum of squares) rows, the rows of an image consecutive
+// (rows_per_img = 1: what ried_conv2d leaves with stats_post = 3)  ->  save [nimg][2][C] = (mean, 1/sqrt(var+eps)).
+__global__ void bn_finalize_images_kernel(const float* __restrict__ stats, int rows_per_img, int nimg, int C,
+                                          float count, float eps, float* __restrict__ save) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nimg * C) return;
+  const int n = i / C, c = i - n * C;
+  const float* p = stats + (long long)n * rows_per_img * 2 * C + c;
+  float s0 = 0.f, s1 = 0.f;
+  for (int r = 0; r < rows_per_img; ++r) { s0 += p[(long long)r * 2 * C]; s1 += p[(long long)r * 2 * C + C]; }
+  const float mean = s0 / count;
+  const float var = fmaxf(s1 / count - mean * mean, 0.f);
+  save[(long long)n * 2 * C + c] = mean;
+  save[(long long)n * 2 * C + C + c] = rsqrtf(var + eps);
+}
+extern "C" int ried_bn_finalize_images(const float* stats, int rows_per_img, int nimg, int C, long long count,
+                                       float eps, float* save, hipStream_t stream) {
+  RIED_CHECK_ARG(stats && save && rows_per_img > 0 && nimg > 0 && C > 0 && count > 0, "ried_bn_finalize_images: bad arguments");
+  hipLaunchKernelGGL(bn_finalize_images_kernel, dim3(ceil_div((long long)nimg * C, 256)), dim3(256), 0, stream, stats,
+                     rows_per_img, nimg, C, (float)count, eps, save);
+  RIED_CHECK_LAUNCH("ried_bn_finalize_images");
+  return RIED_OK;
+}
+// ried_bn_apply with one statistics set per image: x, y are views of nimg images of npix_per_img pixels each
+extern "C" int ried_bn_apply_images(const void* x, long long ldx, void* y, long long ldy, long long npix_per_img,
+                                    int nimg, int C, const float* save, const float* gamma, const float* beta,
+                                    int relu, int accumulate, hipStream_t stream) {
+  CHECK_VIEW("ried_bn_apply_images", x, ldx, C);
+  CHECK_VIEW("ried_bn_apply_images", y, ldy, C);
+  RIED_CHECK_ARG(save && gamma && beta && npix_per_img > 0 && nimg > 0 && nimg <= 65535 && C <= 8 * EW_THREADS,
+                 "ried_bn_apply_images: bad arguments");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(chan_grid(npix_per_img, C, 2, 8192), nimg), dim3(EW_THREADS), 0, stream,
+                     (const bf16_t*)x, ldx, (bf16_t*)y, ldy, npix_per_img, C, save, gamma, beta, relu, accumulate);
+  RIED_CHECK_LAUNCH("ried_bn_apply_images");
   return RIED_OK;
 }
 

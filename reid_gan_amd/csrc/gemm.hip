@@ -55,6 +55,7 @@ struct GemmEpilogue {
   float mask_slope;
   int stats_post;          // stats = column sums of the final values (bias gradient) instead of the raw results
   int stats_fold;          // > 0: rows are added (float atomics) into row (tile mod stats_fold) of a zeroed buffer
+  int stats_img_tiles;     // > 0: rows are added into row (pixel tile / stats_img_tiles) = the tile's image
   int stats_zero;          // f > 1: the caller sized the buffer for f times as many rows as the stats_rows this
   int stats_rows;          //        launch writes; the writer of row t also zeroes rows stats_rows + t*(f-1) .. + f-2
   BnFinalize fin;          // fin.counter != null: the last block to finish turns the stats rows into BN statistics
@@ -409,7 +410,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
     __syncthreads();
     if (wn == 0 && (lane & 15) == 0) {
       long long ridx = (long long)by * ntiles_n + tn;
-      if (E.stats_fold) ridx %= E.stats_fold;
+      if (E.stats_img_tiles) ridx = tn / E.stats_img_tiles;
+      else if (E.stats_fold) ridx %= E.stats_fold;
       float* row = E.stats + ridx * 2 * P.M;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -421,7 +423,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
             float s0 = ssum[i][q], s1 = ssq[i][q];
 #pragma unroll
             for (int w = 0; w < WN - 1; ++w) { s0 += red[w * 2 * BM + ml]; s1 += red[w * 2 * BM + BM + ml]; }
-            if (E.stats_fold) {            // few rows for the consumer to re-reduce: a short chain of atomics each
+            if (E.stats_fold || E.stats_img_tiles) {     // few rows: a short chain of atomics each
               __hip_atomic_fetch_add(&row[m], s0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               __hip_atomic_fetch_add(&row[P.M + m], s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else if (E.fin.counter) {           // read by the last block of this launch: write-through
@@ -594,8 +596,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 
         for (int w = 0; w < NW; ++w) t += red[(w * 2 + k) * HM + ch];
         if (mm < P.M) {
           long long ridx = (long long)by * ntiles_n + tn;
-          if (E.stats_fold) {
-            __hip_atomic_fetch_add(E.stats + (ridx % E.stats_fold) * 2 * P.M + (long long)k * P.M + mm, t,
+          if (E.stats_fold || E.stats_img_tiles) {
+            const long long row = E.stats_img_tiles ? tn / E.stats_img_tiles : ridx % E.stats_fold;
+            __hip_atomic_fetch_add(E.stats + row * 2 * P.M + (long long)k * P.M + mm, t,
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           } else {
             E.stats[ridx * 2 * P.M + (long long)k * P.M + mm] = t;
@@ -1699,6 +1702,8 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   RIED_CHECK_ARG(!mask || (ldmask % 4 == 0 && ldmask >= Cout && ((uintptr_t)mask % 8) == 0), "ried_conv2d: bad mask view");
   P.E.mask = (const bf16_t*)mask; P.E.ld_mask = ldmask; P.E.mask_slope = mask_slope; P.E.stats_post = stats_post == 1;
   P.E.stats_fold = stats_post == 2 ? ried_bn_fold_rows() : 0;
+  const bool img_stats = stats_post == 3;      // one row per image; every kernel below sets its tiles per image
+  RIED_CHECK_ARG(!img_stats || (stats && !fin), "ried_conv2d: per-image statistics need a stats buffer");
   RIED_CHECK_ARG(!sub || (stats && gout && ld_sub % 4 == 0 && ld_gout % 4 == 0 && ((uintptr_t)sub % 16) == 0 &&
                           ((uintptr_t)gout % 8) == 0),
                  "ried_conv2d: bad perceptual-tap arguments");
@@ -1715,7 +1720,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   // 3x3 stride-1 layers on maps of whole 16x16 tiles: the halo-tile kernel (the input tile serves all nine taps)
   if (g_forced_tile[0] == 0 && P.E.staged && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 &&
       Cin % 64 == 0 && H % 8 == 0 && W % 8 == 0 && a_bytes < 0xFFFF0000ll - 16384 && b_bytes < 0xFFFFF000ll - 1024 &&
-      (nimg % 4 == 0 || (H % 16 == 0 && W % 16 == 0))) {
+      (nimg % 4 == 0 || (H % 16 == 0 && W % 16 == 0)) && (!img_stats || (H % 16 == 0 && W % 16 == 0))) {
     // 16x16 tiles where the map allows; 8x8 tiles of four images otherwise (64 output channels per block there:
     // the small maps have few pixel tiles, and LDS holds two 400-pixel input tiles beside the weight ring)
     const int ts = (H % 16 == 0 && W % 16 == 0) ? 16 : 8;
@@ -1723,7 +1728,8 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     P.tiles_m = ceil_div(Cout, bm);
     const int ntiles = ceil_div(nimg, 256 / (ts * ts)) * (H / ts) * (W / ts);
     // the caller sized the statistics buffer for the other kernel's rows (npix / t.bn): the spare ones are zeroed
-    if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = ntiles; }
+    if (img_stats) P.E.stats_img_tiles = (H / ts) * (W / ts);
+    else if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = ntiles; }
     const dim3 hgrid(P.tiles_m * ntiles);
     if (ts == 8) hipLaunchKernelGGL((conv_halo_kernel<64, 8>), hgrid, dim3(512), 0, stream, P);
     else if (bm == 64 && Cin == 64) hipLaunchKernelGGL((conv_halo_kernel<64, 16, 1>), hgrid, dim3(512), 0, stream, P);
@@ -1739,7 +1745,8 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     const int ts = 16;
     P.tiles_m = ceil_div(Cout, 64);
     const int ntiles = ceil_div(nimg, 256 / (ts * ts)) * (H / ts) * (W / ts);
-    if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * 256 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
+    if (img_stats) P.E.stats_img_tiles = (H / 16) * (W / 16);
+    else if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * 256 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
     const dim3 hgrid(P.tiles_m * ntiles);
     hipLaunchKernelGGL(conv_halo_s2t_kernel<16>, hgrid, dim3(512), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
@@ -1755,12 +1762,18 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     const int bm = Cout <= 32 ? 32 : 64;
     P.tiles_m = ceil_div(Cout, bm);
     const int ntiles = nimg * (H / 16) * (W / 16);
-    if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * 256 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
+    if (img_stats) P.E.stats_img_tiles = (H / 16) * (W / 16);
+    else if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * 256 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
     const dim3 hgrid(P.tiles_m * ntiles);
     if (bm == 32) hipLaunchKernelGGL(conv_halo_d4_kernel<32>, hgrid, dim3(512), 0, stream, P);
     else hipLaunchKernelGGL(conv_halo_d4_kernel<64>, hgrid, dim3(512), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
     return RIED_OK;
+  }
+  if (img_stats) {
+    RIED_CHECK_ARG((Hl * Wl) % t.bn == 0, "ried_conv2d: per-image statistics need maps of whole %d-pixel tiles (%d x %d)",
+                   t.bn, Hl, Wl);
+    P.E.stats_img_tiles = (Hl * Wl) / t.bn;
   }
   P.tiles_m = ceil_div(Cout, t.bm);
   dim3 grid(P.tiles_m * ceil_div(npix, t.bn), phases, 1);

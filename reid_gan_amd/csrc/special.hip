@@ -341,7 +341,11 @@ __global__ void out_conv_fwd_kernel(const float* __restrict__ x, const bf16_t* _
                                     const float* __restrict__ w, float* __restrict__ out, long long npix,
                                     const float* __restrict__ bn_save, const float* __restrict__ gamma,
                                     const float* __restrict__ beta) {
-  // 4 lanes per pixel, 8 channels each
+  // 4 lanes per pixel, 8 channels each; gridDim.y > 1: npix pixels and one statistics set per image
+  x += (long long)blockIdx.y * npix;
+  out += (long long)blockIdx.y * npix;
+  h += (long long)blockIdx.y * npix * ldh;
+  if (bn_save) bn_save += blockIdx.y * 64;
   long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   long long nthreads = (long long)gridDim.x * blockDim.x;
   long long pend = (npix * 4 + nthreads - 1) / nthreads * nthreads;
@@ -410,13 +414,15 @@ __global__ void out_conv_bwd_kernel(const float* __restrict__ x, const bf16_t* _
 
 extern "C" int ried_out_conv_fwd(const float* x, const void* h, long long ldh, const float* w, float* out,
                                  long long npix, const float* bn_save, const float* gamma, const float* beta,
-                                 hipStream_t stream) {
+                                 int bn_images, hipStream_t stream) {
   RIED_CHECK_ARG(x && h && w && out && npix > 0 && ldh % 8 == 0 && ldh >= 32 && ((uintptr_t)h % 16) == 0,
                  "ried_out_conv_fwd: bad arguments");
   RIED_CHECK_ARG((!bn_save && !gamma && !beta) || (bn_save && gamma && beta),
                  "ried_out_conv_fwd: bn_save, gamma and beta go together");
-  hipLaunchKernelGGL(out_conv_fwd_kernel, dim3(ew_grid(npix * 4, SP_THREADS, 2048)), dim3(SP_THREADS), 0, stream, x,
-                     (const bf16_t*)h, ldh, w, out, npix, bn_save, gamma, beta);
+  const int ni = bn_images > 1 ? bn_images : 1;       // per-image statistics: bn_save is [bn_images][2][32]
+  RIED_CHECK_ARG(ni == 1 || (bn_save && npix % ni == 0 && ni <= 65535), "ried_out_conv_fwd: bad per-image statistics");
+  hipLaunchKernelGGL(out_conv_fwd_kernel, dim3(ew_grid(npix / ni * 4, SP_THREADS, 2048), ni), dim3(SP_THREADS), 0,
+                     stream, x, (const bf16_t*)h, ldh, w, out, npix / ni, bn_save, gamma, beta);
   RIED_CHECK_LAUNCH("ried_out_conv_fwd");
   return RIED_OK;
 }

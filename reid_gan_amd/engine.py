@@ -126,6 +126,7 @@ class Ctx:
         self.f32_elems = 0            # shared fp32 scratch (BN backward partial rows, column sums)
         self._stats_req: List[Tuple[object, str, int]] = []
         self.chain = False                 # True: no activation gradient has two writers, nothing needs zeroing
+        self.per_image = False             # forward-only plans: BatchNorm statistics per image (see Generator)
         self.build_lane = 0                # lane (stream + scratch set) the layers being built will run on
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
         self.wreds = ops.JobTable(11)      # every weight-gradient slab reduction: one launch (end_backward)
@@ -439,7 +440,13 @@ class ConvBN:
         self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, cin, c.cout, c.kh, c.kw, c.sh, c.sw, deconv)
         self.defer_apply = defer_apply
         assert not (defer_apply and ctx.grads)
-        self.sliced = BN_FOLD and ctx.training and self.raw.npix * cout <= BN_FOLD_MAX_ELEMS and not defer_apply
+        self.per_image = ctx.per_image and ctx.training
+        if self.per_image:     # one (sum, sum of squares) row and one (mean, invstd) pair per image
+            assert not ctx.grads and not bias
+            ctx.stats(self, "img_stats", c.N * 2 * cout, zeroed=True)
+            self.img_save = torch.empty(c.N * 2 * cout, dtype=F32, device=ctx.device)
+        self.sliced = (BN_FOLD and ctx.training and self.raw.npix * cout <= BN_FOLD_MAX_ELEMS and not defer_apply
+                       and not self.per_image)
         if self.sliced:
             self.stat_rows = min(self.stat_rows, ops.bn_fold_rows())
         ctx.stats(self, "stats", self.stat_rows * 2 * cout, zeroed=self.sliced)
@@ -457,6 +464,13 @@ class ConvBN:
 
     def forward(self):
         ctx, c, st = self.ctx, self.core, self.ctx.st
+        if self.per_image:
+            c.conv(self.raw, stats=self.img_stats, stats_post=3)
+            ops.bn_finalize_images(self.img_stats, 1, c.N, c.cout, c.Ho * c.Wo, self.img_save)
+            if not self.defer_apply:
+                ops.bn_apply_images(self.raw, self.out.v, self.img_save, st.p[self.bn + ".weight"],
+                                    st.p[self.bn + ".bias"], relu=self.act, accumulate=self.accumulate)
+            return
         # A conv bias in front of a train-mode BatchNorm cancels in the normalised output: the conv runs without
         # it and running_mean, the one place it shows, gets momentum * bias afterwards.
         if self.sliced:
@@ -519,6 +533,10 @@ class ConvBNC1:
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
         self.stat_rows = ops.conv_c1_stat_rows(N, H, W, cout, 2)
         ctx.stats(self, "stats", self.stat_rows * 2 * cout)
+        self.per_image = ctx.per_image and ctx.training
+        if self.per_image:     # the kernel writes one row per 256 consecutive pixels: whole rows per image
+            assert self.stat_rows % N == 0 and (self.Ho * self.Wo) % 256 == 0, "per-image statistics: map too small"
+            self.img_save = torch.empty(N * 2 * cout, dtype=F32, device=ctx.device)
         self.fold = (torch.empty(ops.bn_finalize_fold_floats(cout), dtype=F32, device=ctx.device)
                      if self.stat_rows > 1024 else None)
         if ctx.grads:
@@ -531,6 +549,12 @@ class ConvBNC1:
         ctx, st, bn = self.ctx, self.ctx.st, self.prefix + ".bn"
         self.x = x
         w = st.p[self.prefix + ".conv.weight"]
+        if self.per_image:
+            ops.conv_c1_fwd(x, w, self.raw, 2, stats=self.stats)
+            ops.bn_finalize_images(self.stats, self.stat_rows // self.N, self.N, self.cout, self.Ho * self.Wo,
+                                   self.img_save)
+            ops.bn_apply_images(self.raw, self.out.v, self.img_save, st.p[bn + ".weight"], st.p[bn + ".bias"], relu=True)
+            return
         if ctx.training:
             ops.conv_c1_fwd(x, w, self.raw, 2, stats=self.stats)
             ops.bn_finalize(self.stats, self.stat_rows, self.cout, self.raw.npix, self.save, st.b[bn + ".running_mean"],
@@ -832,11 +856,19 @@ class Generator:
     """RIGAN (src/rinet.py:34-92) for a fixed (N, H, W).  x and the output are fp32 (N,1,H,W)."""
 
     def __init__(self, state: State, N: int, H: int, W: int, grads=True, training=True, device="cuda",
-                 out: Optional[torch.Tensor] = None):
-        """out: where the (N,1,H,W) fp32 result goes (default: an own buffer)."""
+                 out: Optional[torch.Tensor] = None, per_image_stats: bool = False):
+        """out: where the (N,1,H,W) fp32 result goes (default: an own buffer).
+        per_image_stats (forward-only, train-mode BatchNorm): every image of the batch is normalised with its own
+        statistics, i.e. the batch is N independent batch-1 forwards - what the reference's evaluation loop
+        computes (src/test.py:107-131: batch-1 loader, the model left in train mode).  The running statistics are
+        not updated.  Needs H, W divisible by 256 (the smallest maps must consist of whole pixel tiles)."""
         assert H % 16 == 0 and W % 16 == 0, "RIGAN needs H, W divisible by 16 (skip connections must line up)"
         self.st = state
         self.ctx = ctx = Ctx(state, device, grads, training)
+        if per_image_stats:
+            if grads or not training or H % 256 or W % 256:
+                raise ValueError("per-image statistics: forward-only train-mode plans on H, W divisible by 256")
+            ctx.per_image = True
         self.N, self.H, self.W = N, H, W
         h2, w2, h4, w4, h8, w8, h16, w16 = H // 2, W // 2, H // 4, W // 4, H // 8, W // 8, H // 16, W // 16
         self.cat2 = Slot(ctx.act(N, h2, w2, 96))        # cat(conv1 (32), deconv1 (64))   src/rinet.py:89
@@ -876,8 +908,10 @@ class Generator:
         self.conv1.forward(x)
         self.body.forward()
         if self.last.defer_apply:
+            pi = self.last.per_image
             ops.out_conv_fwd(x, self.last.raw, self.st.p["out_conv.weight"], self.out,
-                             bn=(self.last.save, self.st.p["deconv2.bn.weight"], self.st.p["deconv2.bn.bias"]))
+                             bn=(self.last.img_save if pi else self.last.save, self.st.p["deconv2.bn.weight"],
+                                 self.st.p["deconv2.bn.bias"]), bn_images=self.N if pi else 0)
         else:
             ops.out_conv_fwd(x, self.hlast.v, self.st.p["out_conv.weight"], self.out)
         return self.out

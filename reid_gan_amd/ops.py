@@ -279,6 +279,17 @@ def bn_apply(x: View, y: View, save, gamma, beta, relu=True, accumulate=False):
                       int(accumulate), _stream())
 
 
+def bn_finalize_images(stats, rows_per_img: int, nimg: int, C: int, count: int, save, eps=1e-5):
+    """Per-image (mean, invstd) [nimg][2][C] from partial rows [nimg * rows_per_img][2][C]."""
+    lib.ried_bn_finalize_images(_p(stats), rows_per_img, nimg, C, count, eps, _p(save), _stream())
+
+
+def bn_apply_images(x: View, y: View, save, gamma, beta, relu=True, accumulate=False):
+    """bn_apply with one statistics set per image of the views."""
+    lib.ried_bn_apply_images(x.ptr, x.ld, y.ptr, y.ld, x.H * x.W, x.N, x.C, _p(save), _p(gamma), _p(beta), int(relu),
+                             int(accumulate), _stream())
+
+
 def bn_backward(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma=None, dbeta=None, relu=True,
                 accumulate=False, counter: Optional[torch.Tensor] = None):
     """scratch: fp32, at least bn_backward_scratch_floats(C) elements.  counter: a zeroed int32 element owned by
@@ -423,10 +434,12 @@ def axpy_f32(y: torch.Tensor, x: torch.Tensor, alpha: float):
     lib.ried_axpy_f32(_p(y), _p(x), alpha, y.numel(), _stream())
 
 
-def out_conv_fwd(x: torch.Tensor, h: View, w: torch.Tensor, out: torch.Tensor, bn=None):
-    """bn = (save, gamma, beta): h is the raw conv output and BatchNorm + ReLU are applied on the fly."""
+def out_conv_fwd(x: torch.Tensor, h: View, w: torch.Tensor, out: torch.Tensor, bn=None, bn_images: int = 0):
+    """bn = (save, gamma, beta): h is the raw conv output and BatchNorm + ReLU are applied on the fly;
+    bn_images > 1: save holds one statistics set per image."""
     save, gamma, beta = bn if bn is not None else (None, None, None)
-    lib.ried_out_conv_fwd(_p(x), h.ptr, h.ld, _p(w), _p(out), h.npix, _p(save), _p(gamma), _p(beta), _stream())
+    lib.ried_out_conv_fwd(_p(x), h.ptr, h.ld, _p(w), _p(out), h.npix, _p(save), _p(gamma), _p(beta), bn_images,
+                          _stream())
 
 
 def out_conv_bwd(x, h: View, w, dout, dh: View, dw):

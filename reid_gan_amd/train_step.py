@@ -262,10 +262,14 @@ class InferenceEngine:
     measure.compute_measure per slice, from one read of x, y and pred."""
 
     def __init__(self, g_sd: Dict[str, torch.Tensor], batch: int, H: int, W: int, device="cuda", train_mode_bn=True,
-                 lo=-160.0, hi=240.0, use_graph=True):
+                 lo=-160.0, hi=240.0, use_graph=True, per_slice_stats=False):
+        """per_slice_stats: BatchNorm statistics of every slice on its own, as in the reference's loop over a
+        batch-1 loader (src/test.py:107-131), inside the batched kernels (H, W divisible by 256).  Default: the
+        generator applied to the batch (statistics over the batch)."""
         ops.require_gpu()
         self.gs = State(g_sd, device)
-        self.G = Generator(self.gs, batch, H, W, grads=False, training=train_mode_bn, device=device)
+        self.G = Generator(self.gs, batch, H, W, grads=False, training=train_mode_bn, device=device,
+                           per_image_stats=per_slice_stats)
         self.B, self.H, self.W, self.lo, self.hi = batch, H, W, lo, hi
         self.sums = torch.zeros(batch, 4, dtype=F32, device=device)
         self.x = torch.zeros(batch, 1, H, W, dtype=F32, device=device)

@@ -382,6 +382,37 @@ def test_slice_inference_is_the_batch_one_loop():
     act_close(pred2.cpu(), pred, "second run", mx=5e-3, mean=5e-4)
 
 
+def test_per_slice_statistics_inside_the_batched_kernels():
+    """InferenceEngine(per_slice_stats=True): one batched pass whose BatchNorm layers normalise every slice with its
+    own statistics - the reference's batch-1 evaluation loop.  Against the batch-1 engine slice by slice (same
+    kernels, same arithmetic up to the order of the statistics sums), against the oracle's forward of each slice
+    alone, and unlike the whole-batch statistics."""
+    sd = g_state()
+    B, H = 3, 256
+    x, y = synth_batch(B, H, seed=56)
+    x[1] = x[1] * 0.25 - 600.0
+    x[2] = x[2] * 1.5 + 300.0
+    eng = InferenceEngine(sd, B, H, H, per_slice_stats=True)
+    pred, sums = eng.run(x.to(DEV), y.to(DEV))
+    pred, got = pred.cpu().clone(), eng.measures(sums)
+    one = InferenceEngine(sd, 1, H, H)
+    worst = 0.0
+    for i in range(B):
+        p1, s1 = one.run(x[i:i + 1].to(DEV), y[i:i + 1].to(DEV))
+        act_close(pred[i:i + 1], p1.cpu(), f"slice {i} vs the batch-1 engine", mx=5e-3, mean=5e-4)
+        worst = max(worst, (pred[i:i + 1] - p1.cpu()).abs().mean().item())
+        m1 = one.measures(s1)[0]
+        for a, b in zip(got[i][1], m1[1]):
+            assert abs(a - b) <= 2e-3 * abs(b) + 1e-5, (i, got[i], m1)
+        with torch.no_grad():
+            ref = O.rigan_forward(O.Params({k: v.clone() for k, v in sd.items()}), x[i:i + 1], True)
+        act_close(pred[i:i + 1], ref, f"slice {i} vs the oracle's batch-1 forward", mx=2e-2, mean=5e-3)
+    whole, _ = InferenceEngine(sd, B, H, H).run(x.to(DEV), y.to(DEV))
+    assert (whole.cpu() - pred).abs().mean().item() > 10 * worst + 1e-3
+    with pytest.raises(ValueError):
+        InferenceEngine(sd, 2, 64, 64, per_slice_stats=True)          # maps too small for whole pixel tiles
+
+
 def test_inference_metrics_vs_oracle():
     sd = g_state()
     B, H = 2, 128
