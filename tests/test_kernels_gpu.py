@@ -242,6 +242,44 @@ def test_deconv_4x4_stride2_halo_kernel(cin, cout, N, H, W):
         close(a, b, 4e-3, what + " vs general kernel")
 
 
+@pytest.mark.parametrize("cin,cout,k,s,tr,H", [(64, 64, 3, 1, False, 32), (64, 32, 1, 1, False, 16), (48, 40, 3, 2, False, 32),
+                                               (96, 32, 4, 2, True, 16), (128, 64, 3, 1, False, 16)])
+def test_per_image_statistics_rows_and_apply(cin, cout, k, s, tr, H):
+    """stats_post = 3: one (sum, sum of squares) row per image from every convolution kernel (general, halo-tile,
+    four-phase), then ried_bn_finalize_images / ried_bn_apply_images = train-mode BatchNorm + ReLU of each image on
+    its own (the batch-1 evaluation loop of src/test.py:107-131 on a batch)."""
+    N, p = 3, (1 if k > 1 else 0)
+    x = r(N, cin, H, H, seed=80)
+    x[1] = x[1] * 3 + 1                                     # images with different statistics
+    if tr:
+        w = r(cin, cout, k, k, seed=81, scale=(cin * k) ** -0.5)
+        ref = F.conv_transpose2d(x, w, None, s, p)
+        wp = pack(w.permute(1, 0, 2, 3))
+    else:
+        w = r(cout, cin, k, k, seed=81, scale=(cin * k * k) ** -0.5)
+        ref = F.conv2d(x, w, None, s, p)
+        wp = pack(w)
+    Ho = ref.shape[-1]
+    for force in ((0, 1, 0), (-1, 0, 0)):                   # with and without the halo-tile kernels
+        lib.ried_conv2d_force_tile(*force)
+        try:
+            yv = ops.new_view(N, Ho, Ho, cout)
+            stats = torch.zeros(N, 2, cout, device=DEV)
+            ops.conv2d(to_view(x), wp, yv, k, k, s, s, p, p, transposed=tr, stats=stats, stats_post=3)
+        finally:
+            lib.ried_conv2d_force_tile(0, 0, 0)
+        close(stats[:, 0].cpu(), ref.sum((2, 3)), 3e-3, "per-image sums")
+        close(stats[:, 1].cpu(), (ref * ref).sum((2, 3)), 3e-3, "per-image sums of squares")
+    save = torch.empty(N, 2, cout, device=DEV)
+    ops.bn_finalize_images(stats, 1, N, cout, Ho * Ho, save)
+    gamma, beta = 1 + 0.1 * r(cout, seed=82), 0.1 * r(cout, seed=83)
+    out = ops.new_view(N, Ho, Ho, cout)
+    ops.bn_apply_images(yv, out, save, gamma.to(DEV), beta.to(DEV), relu=True)
+    raw = from_view(yv)
+    want = torch.cat([F.relu(F.batch_norm(raw[i:i + 1], None, None, gamma, beta, True, 0.1, 1e-5)) for i in range(N)])
+    close(from_view(out), want, 2e-2, "per-image BatchNorm + ReLU")
+
+
 def test_bn_finalize_folds_many_rows():
     """Thousands of partial rows (512x512 inference) go through the two-step reduction: same statistics."""
     g = torch.Generator().manual_seed(3)
