@@ -619,6 +619,19 @@ def test_pool(mode):
     close(from_view(dxv), x.grad, 1e-2, "dx")
 
 
+@pytest.mark.parametrize("N,C,H,W", [(4, 64, 128, 64), (2, 256, 64, 128)])
+def test_average_pool_on_large_maps(N, C, H, W):
+    """Maps of a million 8-channel chunks or more take the strip kernel (inference sizes): same result, borders
+    included, in a channel slice of a wider buffer."""
+    x = r(N, C, H, W, seed=22)
+    y = F.avg_pool2d(x, 3, 1, 1)
+    big = ops.new_view(N, H, W, C + 16, zero=True)
+    ops.pool_fwd(to_view(x), big.slice(8, 8 + C), 2)
+    got = from_view(big)
+    close(got[:, 8:8 + C], y, 4e-3, "strip average pool")
+    assert got[:, :8].abs().max() == 0 and got[:, 8 + C:].abs().max() == 0
+
+
 def test_maxpool_ties_first_max():
     x = torch.zeros(1, 8, 4, 4)
     y = F.max_pool2d(x.clone().requires_grad_(True), 3, 2, 1)
