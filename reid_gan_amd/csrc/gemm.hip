@@ -1091,8 +1091,10 @@ __global__ __launch_bounds__(512, NBB == 1 ? 4 : 2) void conv_halo_kernel(const 
 // ---------------------------------------------------------------------------
 struct S2tStep { int phase, wtap, shift_i, shift_j; };
 // phase = 2*(row parity) + column parity; weight tap r*3+s with (parity + 1 - r) even; input shift (parity+1-r)/2
-__device__ constexpr S2tStep S2T_STEPS[9] = {{0, 4, 0, 0}, {1, 3, 0, 1}, {1, 5, 0, 0}, {2, 1, 1, 0}, {2, 7, 0, 0},
-                                             {3, 0, 1, 1}, {3, 2, 1, 0}, {3, 6, 0, 1}, {3, 8, 0, 0}};
+// Ordered by input shift: steps with the same shift reuse the pixel fragments in registers (four fragment loads
+// per slab instead of nine).
+__device__ constexpr S2tStep S2T_STEPS[9] = {{0, 4, 0, 0}, {1, 5, 0, 0}, {2, 7, 0, 0}, {3, 8, 0, 0}, {1, 3, 0, 1},
+                                             {3, 6, 0, 1}, {2, 1, 1, 0}, {3, 2, 1, 0}, {3, 0, 1, 1}};
 
 template <int TS>
 __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams P) {
@@ -1180,11 +1182,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams 
     hr0[j] = il * HRI + (p / TS) * TWP + (p % TS);
   }
   bf16x8_t fa[2][TM], fb[2][TN];
-  auto load_frags = [&](int stage, int bbuf, int toff, int ks) {
+  auto load_frags = [&](int stage, int bbuf, int toff, int ks, bool new_pixels) {
     const char* sa = sA + stage * ABUF + wm * (BM / 2) * 128 + frow;
     const char* sb = sB + bbuf * BBUF;
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + (ks ? sw1 : sw0));
+    if (!new_pixels) return;              // same shift as the step before: the pixel fragments are still in fb
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       int hr = hr0[j] + toff;
@@ -1207,11 +1210,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams 
       __builtin_amdgcn_s_barrier();
       const int toff = S2T_STEPS[step].shift_i * TWP + S2T_STEPS[step].shift_j;
       const int ph = S2T_STEPS[step].phase;
-      load_frags(step % 3, slab & 1, toff, 0);
+      const bool newp = step == 0 || S2T_STEPS[step].shift_i != S2T_STEPS[step - (step ? 1 : 0)].shift_i ||
+                        S2T_STEPS[step].shift_j != S2T_STEPS[step - (step ? 1 : 0)].shift_j;
+      load_frags(step % 3, slab & 1, toff, 0, newp);
       if (step < 7) issueA(slab, step + 2, (step + 2) % 3);
       else issueA(slab + 1, step - 7, (step + 2) % 3);
       if (step < NLB) issueB(slab + 1, step);
-      load_frags(step % 3, slab & 1, toff, 1);
+      load_frags(step % 3, slab & 1, toff, 1, newp);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1264,11 +1269,20 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams 
 // BM output channels per block (32 or 64); the weight stage always holds 64 rows (rows past Cout load as zeros).
 // ---------------------------------------------------------------------------
 struct D4Step { int phase, wtap, shift_i, shift_j; };
+// Phase (a, b) = 2a + b uses rows r in {1, 3} (a = 0) or {0, 2} (a = 1) and columns s likewise.  The sixteen
+// products are ordered by input shift: steps that read the same shifted pixels follow each other and reuse the
+// pixel fragments in registers (nine fragment loads per slab instead of sixteen); neighbours in the list add into
+// different phases' accumulators.
 __device__ constexpr D4Step D4_STEPS[16] = {
-    {0, 5, 0, 0},  {0, 7, 0, -1},  {0, 13, -1, 0}, {0, 15, -1, -1},      // a = 0, b = 0: r in {1, 3}, s in {1, 3}
-    {1, 4, 0, 1},  {1, 6, 0, 0},   {1, 12, -1, 1}, {1, 14, -1, 0},       // a = 0, b = 1: r in {1, 3}, s in {0, 2}
-    {2, 1, 1, 0},  {2, 3, 1, -1},  {2, 9, 0, 0},   {2, 11, 0, -1},       // a = 1, b = 0: r in {0, 2}, s in {1, 3}
-    {3, 0, 1, 1},  {3, 2, 1, 0},   {3, 8, 0, 1},   {3, 10, 0, 0}};       // a = 1, b = 1: r in {0, 2}, s in {0, 2}
+    {0, 5, 0, 0},   {1, 6, 0, 0},   {2, 9, 0, 0},  {3, 10, 0, 0},        // shift ( 0,  0)
+    {0, 7, 0, -1},  {2, 11, 0, -1},                                      // shift ( 0, -1)
+    {0, 13, -1, 0}, {1, 14, -1, 0},                                      // shift (-1,  0)
+    {0, 15, -1, -1},                                                     // shift (-1, -1)
+    {1, 4, 0, 1},   {3, 8, 0, 1},                                        // shift ( 0,  1)
+    {1, 12, -1, 1},                                                      // shift (-1,  1)
+    {2, 1, 1, 0},   {3, 2, 1, 0},                                        // shift ( 1,  0)
+    {2, 3, 1, -1},                                                       // shift ( 1, -1)
+    {3, 0, 1, 1}};                                                       // shift ( 1,  1)
 
 template <int BM>
 __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P) {
@@ -1351,11 +1365,12 @@ __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P
     hr0[j] = (p / TS + 1) * TWP + (p % TS) + 1;
   }
   bf16x8_t fa[2][TM], fb[2][TN];
-  auto load_frags = [&](int stage, int bbuf, int toff, int ks) {
+  auto load_frags = [&](int stage, int bbuf, int toff, int ks, bool new_pixels) {
     const char* sa = sA + stage * ABUF + wm * (BM / 2) * 128 + frow;
     const char* sb = sB + bbuf * BBUF;
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + (ks ? sw1 : sw0));
+    if (!new_pixels) return;              // same shift as the step before: the pixel fragments are still in fb
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       int hr = hr0[j] + toff;
@@ -1388,11 +1403,13 @@ __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P
       __builtin_amdgcn_s_barrier();
       const int toff = D4_STEPS[step].shift_i * TWP + D4_STEPS[step].shift_j;
       const int ph = D4_STEPS[step].phase;
-      load_frags(step % NSA, slab & 1, toff, 0);
+      const bool newp = step == 0 || D4_STEPS[step].shift_i != D4_STEPS[step - (step ? 1 : 0)].shift_i ||
+                        D4_STEPS[step].shift_j != D4_STEPS[step - (step ? 1 : 0)].shift_j;
+      load_frags(step % NSA, slab & 1, toff, 0, newp);
       if (step < NSTEP - 3) issueA(slab, step + 3, (step + 3) % NSA);
       else issueA(slab + 1, step + 3 - NSTEP, (step + 3) % NSA);
       if (step < NLB) issueB(slab + 1, step);
-      if (both) load_frags(step % NSA, slab & 1, toff, 1);
+      if (both) load_frags(step % NSA, slab & 1, toff, 1, newp);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
