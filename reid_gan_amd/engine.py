@@ -127,6 +127,7 @@ class Ctx:
         self._stats_req: List[Tuple[object, str, int]] = []
         self.chain = False                 # True: no activation gradient has two writers, nothing needs zeroing
         self.per_image = False             # forward-only plans: BatchNorm statistics per image (see Generator)
+        self.dx_group: Optional["InputGradGroup"] = None     # open group of sibling 1x1 layers (see InputGradGroup)
         self.build_lane = 0                # lane (stream + scratch set) the layers being built will run on
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
         self.wreds = ops.JobTable(11)      # every weight-gradient slab reduction: one launch (end_backward)
@@ -430,8 +431,10 @@ class ConvBN:
         self.bn = bn_key or (prefix + ".bn")
         self.bias_key = conv_key + ".bias" if bias else None
         self.act, self.shared = act, shared
-        self.core = ConvCore(ctx, conv_key + ".weight", cin, cout, k, stride, pad, deconv, xin, need_dx,
-                             wgrad_out=wgrad_out)
+        grp = ctx.dx_group
+        grouped = (grp is not None and ctx.grads and need_dx and not deconv and grp.wants(xin, k, stride, pad))
+        self.core = ConvCore(ctx, conv_key + ".weight", cin, cout, k, stride, pad, deconv, xin,
+                             need_dx and not grouped, wgrad_out=wgrad_out)
         c = self.core
         assert out.shape == (c.N, c.Ho, c.Wo, cout), (prefix, out.shape, (c.N, c.Ho, c.Wo, cout))
         self.out, self.accumulate = out, accumulate
@@ -459,7 +462,10 @@ class ConvBN:
                 ctx.need_f32(ops.colsum_scratch_floats(cout))
             # the gradient w.r.t. the conv output keeps its own buffer, so that the weight gradient can wait for
             # the grouped launch at the end of the backward pass
-            self.draw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
+            if grouped:
+                grp.join(self)         # the group hands out a channel slice of its buffer as self.draw when it closes
+            else:
+                self.draw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
             c.defer_wgrad(lambda: self.draw)
 
     def forward(self):
@@ -518,6 +524,63 @@ class ConvBN:
         c = self.core
         if c.need_dx:
             c.dgrad(self.draw, c.xin.g)
+
+
+class InputGradGroup:
+    """Sibling 1x1 convolutions that read the same tensor - the first layers of an Inception block's branches and its
+    identity_downsample (src/rinet.py:99-103, 225-233).  Their gradients w.r.t. that tensor are ONE transposed 1x1
+    convolution over the concatenation of their pre-BatchNorm gradients (which they write into channel slices of
+    one buffer) with their weights concatenated along K, instead of one accumulating launch - a read-modify-write
+    of the whole input gradient - per sibling."""
+
+    def __init__(self, ctx: Ctx, xin: Slot):
+        self.ctx, self.xin, self.members = ctx, xin, []
+        self.drawcat: Optional[View] = None
+
+    def wants(self, xin: Slot, k, stride, pad) -> bool:
+        a, b = self.xin, xin
+        return (a.act is b.act and (a.c0, a.c1, a.n0, a.n1) == (b.c0, b.c1, b.n0, b.n1) and
+                _pair(k) == (1, 1) and _pair(stride) == (1, 1) and _pair(pad) == (0, 0))
+
+    def join(self, layer: "ConvBN"):
+        self.members.append(layer)
+
+    def close(self):
+        """Allocate the shared gradient buffer, hand out its slices, register the packs of the concatenated
+        backward weights; returns the layer to put FIRST in the block's sequence (it runs last in backward)."""
+        ctx = self.ctx
+        ctx.dx_group = None
+        assert len(self.members) >= 1
+        N, H, W, cin = self.xin.shape
+        total = sum(m.core.cout for m in self.members)
+        self.drawcat = ops.new_view(N, H, W, total, ctx.device)
+        self.wcat = torch.empty(cin * total, dtype=torch.bfloat16, device=ctx.device)     # [cin][total]
+        c0 = 0
+        for m in self.members:
+            co = m.core.cout
+            m.draw = self.drawcat.slice(c0, c0 + co)
+            if ctx.st is not None:      # master (Cout, Cin, 1, 1) -> column slice [c0, c0 + Cout) of row c_in
+                ctx.add_pack(ctx.st.p[m.core.wname], self.wcat[c0:], cin, 1, 1, co, 1, 1, 1, cin, dst_pitch=total)
+            c0 += co
+        return self
+
+    def forward(self):
+        pass
+
+    def backward(self):
+        ops.conv2d(self.drawcat, self.wcat, self.xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True)
+
+
+def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
+    if not ctx.grads:
+        return None
+    ctx.dx_group = InputGradGroup(ctx, xin)
+    return ctx.dx_group
+
+
+def close_input_grad_group(grp: Optional[InputGradGroup], seq: "Seq"):
+    if grp is not None:
+        seq.layers.insert(0, grp.close())
 
 
 class ConvBNC1:
@@ -741,6 +804,7 @@ def _residual_head(ctx, seq, prefix, xin: Slot, out: Slot, cin, cout, has_ds):
 def inception_a(ctx, prefix, xin: Slot, out: Slot, cin, has_ds) -> Seq:
     """src/rinet.py:207-252: out = cat(32|32|48|16) + identity."""
     s = Seq()
+    grp = open_input_grad_group(ctx, xin)
     _residual_head(ctx, s, prefix, xin, out, cin, 128, has_ds)
     with _Lane(ctx, 0) as b0:      # the longest branch on the caller's stream
         _chain(ctx, b0, prefix, [("branch3x3dbl_1", cin, 32, 1, 1, 0), ("branch3x3dbl_2", 32, 48, 3, 1, 1),
@@ -756,12 +820,14 @@ def inception_a(ctx, prefix, xin: Slot, out: Slot, cin, has_ds) -> Seq:
         b3.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
         _chain(ctx, b3, prefix, [("branch_pool", cin, 16, 1, 1, 0)], pooled, out.sub(112, 128), accumulate=True)
     s.add(Par(ctx, [b0, b1, b2, b3]))
+    close_input_grad_group(grp, s)
     return s
 
 
 def inception_c(ctx, prefix, xin: Slot, out: Slot, cin, c7, has_ds) -> Seq:
     """src/rinet.py:293-347: out = cat(64|64|64|64) + identity."""
     s = Seq()
+    grp = open_input_grad_group(ctx, xin)
     _residual_head(ctx, s, prefix, xin, out, cin, 256, has_ds)
     h, v = ((1, 7), 1, (0, 3)), ((7, 1), 1, (3, 0))
     with _Lane(ctx, 0) as b0:
@@ -779,12 +845,14 @@ def inception_c(ctx, prefix, xin: Slot, out: Slot, cin, c7, has_ds) -> Seq:
         b3.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
         _chain(ctx, b3, prefix, [("branch_pool", cin, 64, 1, 1, 0)], pooled, out.sub(192, 256), accumulate=True)
     s.add(Par(ctx, [b0, b1, b2, b3]))
+    close_input_grad_group(grp, s)
     return s
 
 
 def inception_e(ctx, prefix, xin: Slot, out: Slot, cin, has_ds) -> Seq:
     """src/rinet.py:389-445: out = cat(160 | 192,192 | 192,192 | 96) + identity."""
     s = Seq()
+    grp = open_input_grad_group(ctx, xin)
     _residual_head(ctx, s, prefix, xin, out, cin, 1024, has_ds)
     N, H, W, _ = xin.shape
     with _Lane(ctx, 0) as b0:
@@ -807,6 +875,7 @@ def inception_e(ctx, prefix, xin: Slot, out: Slot, cin, has_ds) -> Seq:
         b4.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
         _chain(ctx, b4, prefix, [("branch_pool", cin, 96, 1, 1, 0)], pooled, out.sub(928, 1024), accumulate=True)
     s.add(Par(ctx, [b0, b1, b2, b4]))
+    close_input_grad_group(grp, s)
     return s
 
 
