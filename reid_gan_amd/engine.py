@@ -892,6 +892,7 @@ def _grid_tail(ctx, s, prefix, xin: Slot, out_slice: Slot, cin, cs, decoder):
 def inception_b(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
     """src/rinet.py:254-291: cat(64 | 64 | maxpool(cin) or sample(128))."""
     k = 4 if decoder else 3
+    grp = None if decoder else open_input_grad_group(ctx, xin)     # (decoder blocks start with 1x1 transposed convs)
     with _Lane(ctx, 0) as b0:
         _chain(ctx, b0, prefix, [("branch3x3dbl_1", cin, 32, 1, 1, 0), ("branch3x3dbl_2", 32, 48, 3, 1, 1),
                                  ("branch3x3dbl_3", 48, 64, k, 2, 1)], xin, out.sub(64, 128), deconv=decoder)
@@ -901,12 +902,15 @@ def inception_b(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
     cs = 128 if decoder else cin
     with _Lane(ctx, 2) as b2:
         _grid_tail(ctx, b2, prefix, xin, out.sub(128, 128 + cs), cin, cs, decoder)
-    return Seq([Par(ctx, [b0, b1, b2])])
+    s = Seq([Par(ctx, [b0, b1, b2])])
+    close_input_grad_group(grp, s)
+    return s
 
 
 def inception_d(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
     """src/rinet.py:349-387: cat(128 | 128 | maxpool(cin) or sample(256))."""
     k = 4 if decoder else 3
+    grp = None if decoder else open_input_grad_group(ctx, xin)     # (decoder blocks start with 1x1 transposed convs)
     with _Lane(ctx, 0) as b0:
         _chain(ctx, b0, prefix, [("branch7x7x3_1", cin, 128, 1, 1, 0), ("branch7x7x3_2", 128, 128, (1, 7), 1, (0, 3)),
                                  ("branch7x7x3_3", 128, 128, (7, 1), 1, (3, 0)),
@@ -917,7 +921,9 @@ def inception_d(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
     cs = 256 if decoder else cin
     with _Lane(ctx, 2) as b2:
         _grid_tail(ctx, b2, prefix, xin, out.sub(256, 256 + cs), cin, cs, decoder)
-    return Seq([Par(ctx, [b0, b1, b2])])
+    s = Seq([Par(ctx, [b0, b1, b2])])
+    close_input_grad_group(grp, s)
+    return s
 
 
 # --------------------------------------------------------------------------- generator
