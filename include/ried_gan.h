@@ -147,9 +147,11 @@ int ried_bn_apply(const void* x, long long ldx, void* y, long long ldy, long lon
  * the folding make the sums depend on the order the conv's blocks finish (last-bit differences between runs). */
 int ried_bn_fold_rows(void);
 int ried_bn_apply_train(const void* x, long long ldx, void* y, long long ldy, long long npix, int C,
-                        const float* stats, int nrows, float eps, float momentum, float* save, float* running_mean,
-                        float* running_var, long long* num_batches_tracked, const float* gamma, const float* beta,
-                        int relu, int accumulate, ried_stream_t stream);
+                        const float* stats, int nrows, int ldstat, float eps, float momentum, float* save,
+                        float* running_mean, float* running_var, long long* num_batches_tracked, const float* gamma,
+                        const float* beta, int relu, int accumulate, ried_stream_t stream);
+/* ldstat: channels per statistics row, 0 = C; larger when the layer is a channel slice of a convolution that served
+ * several layers at once (stats then points at the slice's first channel: rows [nrows][2][ldstat]). */
 /* Per-image train-mode statistics: the evaluation loop of src/test.py:107-131 feeds one slice at a time, so its
  * BatchNorm layers normalise every slice on its own.  stats: [nimg * rows_per_img][2][C] partial rows, the rows of an
  * image consecutive (rows_per_img = 1 after ried_conv2d with stats_post = 3); count = pixels per image;

@@ -593,17 +593,18 @@ struct SliceWalk {
 };
 
 // sums[k][ch] (k < 2, ch < SW) = sum over rows of part[r][k][c0 + ch]; part: [nrows][2][C].  256 threads.
-__device__ __forceinline__ void slice_row_sums(const float* __restrict__ part, int nrows, int C, int c0, int SW,
-                                               float* lds /*256*/, float* sums /*[2][BN_SLICE]*/) {
+// ldp: channels per row of `part` (>= C: the layer's channels may be a slice of a wider statistics buffer)
+__device__ __forceinline__ void slice_row_sums(const float* __restrict__ part, int nrows, int C, int ldp, int c0,
+                                               int SW, float* lds /*256*/, float* sums /*[2][BN_SLICE]*/) {
   const int ncol = 2 * SW, RL = 256 / ncol;
   const int rl = threadIdx.x / ncol, col = threadIdx.x - rl * ncol;
   const int k = col >= SW, ch = col - k * SW;
   if (rl < RL) {
     float a = 0.f;
     if (c0 + ch < C) {
-      const float* src = part + (long long)k * C + c0 + ch;
+      const float* src = part + (long long)k * ldp + c0 + ch;
 #pragma unroll 4
-      for (int r = rl; r < nrows; r += RL) a += src[(long long)r * 2 * C];
+      for (int r = rl; r < nrows; r += RL) a += src[(long long)r * 2 * ldp];
     }
     lds[rl * ncol + col] = a;
   }
@@ -620,14 +621,14 @@ __device__ __forceinline__ void slice_row_sums(const float* __restrict__ part, i
 // of the producing conv; the first pixel group of each slice also writes save and the running statistics.
 __global__ __launch_bounds__(EW_THREADS) void bn_apply_train_kernel(
     const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy, long long npix, int C,
-    const float* __restrict__ stats, int nrows, float eps, float momentum, float* __restrict__ save,
+    const float* __restrict__ stats, int nrows, int ldstat, float eps, float momentum, float* __restrict__ save,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
     const float* __restrict__ gamma, const float* __restrict__ beta, int relu, int accumulate) {
   __shared__ float lds[256];
   __shared__ float sums[2][BN_SLICE];
   __shared__ float ab[2][BN_SLICE];
   SliceWalk w(C);
-  slice_row_sums(stats, nrows, C, w.c0, w.SW, lds, &sums[0][0]);
+  slice_row_sums(stats, nrows, C, ldstat, w.c0, w.SW, lds, &sums[0][0]);
   if (threadIdx.x < w.SW && w.c0 + threadIdx.x < C) {
     const int c = w.c0 + threadIdx.x;
     const float count = (float)npix;
@@ -677,18 +678,20 @@ static inline void slice_grid(long long npix, int C, int iters, int cap, dim3& g
 // stats: [nrows][2][C] folded partial sums (ried_conv2d with stats_post = 2 writes min(BN_FOLD_ROWS, tiles) rows).
 extern "C" int ried_bn_fold_rows() { return BN_FOLD_ROWS; }
 extern "C" int ried_bn_apply_train(const void* x, long long ldx, void* y, long long ldy, long long npix, int C,
-                                   const float* stats, int nrows, float eps, float momentum, float* save,
-                                   float* running_mean, float* running_var, long long* num_batches_tracked,
-                                   const float* gamma, const float* beta, int relu, int accumulate,
-                                   hipStream_t stream) {
+                                   const float* stats, int nrows, int ldstat, float eps, float momentum,
+                                   float* save, float* running_mean, float* running_var,
+                                   long long* num_batches_tracked, const float* gamma, const float* beta, int relu,
+                                   int accumulate, hipStream_t stream) {
   CHECK_VIEW("ried_bn_apply_train", x, ldx, C);
   CHECK_VIEW("ried_bn_apply_train", y, ldy, C);
   RIED_CHECK_ARG(stats && save && gamma && beta && npix > 0 && nrows > 0, "ried_bn_apply_train: bad arguments");
+  if (ldstat <= 0) ldstat = C;
+  RIED_CHECK_ARG(ldstat >= C, "ried_bn_apply_train: ldstat smaller than C");
   dim3 grid;
   slice_grid(npix, C, 2, 8192, grid);
   hipLaunchKernelGGL(bn_apply_train_kernel, grid, dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy,
-                     npix, C, stats, nrows, eps, momentum, save, running_mean, running_var, num_batches_tracked, gamma,
-                     beta, relu, accumulate);
+                     npix, C, stats, nrows, ldstat, eps, momentum, save, running_mean, running_var, num_batches_tracked,
+                     gamma, beta, relu, accumulate);
   RIED_CHECK_LAUNCH("ried_bn_apply_train");
   return RIED_OK;
 }

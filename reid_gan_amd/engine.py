@@ -442,6 +442,7 @@ class ConvBN:
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
         self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, cin, c.cout, c.kh, c.kw, c.sh, c.sw, deconv)
         self.defer_apply = defer_apply
+        self.fused_fwd, self._gstats = None, None      # set by an InputGradGroup that also runs the forward conv
         assert not (defer_apply and ctx.grads)
         self.per_image = ctx.per_image and ctx.training
         if self.per_image:     # one (sum, sum of squares) row and one (mean, invstd) pair per image
@@ -480,11 +481,18 @@ class ConvBN:
         # A conv bias in front of a train-mode BatchNorm cancels in the normalised output: the conv runs without
         # it and running_mean, the one place it shows, gets momentum * bias afterwards.
         if self.sliced:
-            c.conv(self.raw, stats=self.stats, stats_post=2)
-            ops.bn_apply_train(self.raw, self.out.v, self.stats, self.stat_rows, self.save,
+            stats, rows, ldstat = self.stats, self.stat_rows, 0
+            if self.fused_fwd is not None:       # the sibling group's one convolution has produced raw and the sums
+                grp, c0 = self.fused_fwd
+                if self._gstats is None:
+                    self._gstats = grp.stats[c0:]
+                stats, rows, ldstat = self._gstats, grp.stat_rows, grp.total
+            else:
+                c.conv(self.raw, stats=self.stats, stats_post=2)
+            ops.bn_apply_train(self.raw, self.out.v, stats, rows, self.save,
                                st.p[self.bn + ".weight"], st.p[self.bn + ".bias"], st.b[self.bn + ".running_mean"],
                                st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"], relu=self.act,
-                               accumulate=self.accumulate)
+                               accumulate=self.accumulate, ldstat=ldstat)
             if self.bias_key:
                 ops.axpy_f32(st.b[self.bn + ".running_mean"], st.p[self.bias_key], 0.1)
             return
@@ -531,11 +539,15 @@ class InputGradGroup:
     identity_downsample (src/rinet.py:99-103, 225-233).  Their gradients w.r.t. that tensor are ONE transposed 1x1
     convolution over the concatenation of their pre-BatchNorm gradients (which they write into channel slices of
     one buffer) with their weights concatenated along K, instead of one accumulating launch - a read-modify-write
-    of the whole input gradient - per sibling."""
+    of the whole input gradient - per sibling.
+    Forward, for small train-mode layers (the folded-statistics path): the siblings' convolutions are one launch too
+    - weights concatenated along the output channels, each sibling's pre-BatchNorm tensor and statistics a channel
+    slice of the group's - and the input is read once instead of once per sibling."""
 
     def __init__(self, ctx: Ctx, xin: Slot):
         self.ctx, self.xin, self.members = ctx, xin, []
         self.drawcat: Optional[View] = None
+        self.fwd = False
 
     def wants(self, xin: Slot, k, stride, pad) -> bool:
         a, b = self.xin, xin
@@ -562,10 +574,26 @@ class InputGradGroup:
             if ctx.st is not None:      # master (Cout, Cin, 1, 1) -> column slice [c0, c0 + Cout) of row c_in
                 ctx.add_pack(ctx.st.p[m.core.wname], self.wcat[c0:], cin, 1, 1, co, 1, 1, 1, cin, dst_pitch=total)
             c0 += co
+        self.fwd = (ctx.st is not None and ctx.training and not ctx.per_image and len(self.members) >= 2 and
+                    all(m.sliced and not m.bias_key for m in self.members))
+        if self.fwd:
+            self.total = total
+            self.rawcat = ops.new_view(N, H, W, total, ctx.device)
+            self.wfwd = torch.empty(total * cin, dtype=torch.bfloat16, device=ctx.device)           # [total][cin]
+            self.stat_rows = min(ops.conv2d_stat_rows(N, H, W, cin, total, 1, 1), ops.bn_fold_rows())
+            ctx.stats(self, "stats", ops.bn_fold_rows() * 2 * total, zeroed=True)
+            c0 = 0
+            for m in self.members:
+                co = m.core.cout
+                m.raw = self.rawcat.slice(c0, c0 + co)
+                m.fused_fwd = (self, c0)
+                ctx.add_pack(ctx.st.p[m.core.wname], self.wfwd[c0 * cin:], co, 1, 1, cin, cin, 1, 1, 1)
+                c0 += co
         return self
 
     def forward(self):
-        pass
+        if self.fwd:
+            ops.conv2d(self.xin.v, self.wfwd, self.rawcat, 1, 1, 1, 1, 0, 0, stats=self.stats, stats_post=2)
 
     def backward(self):
         ops.conv2d(self.drawcat, self.wcat, self.xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True)

@@ -303,10 +303,11 @@ def bn_fold_rows() -> int:
 
 
 def bn_apply_train(x: View, y: View, stats, nrows, save, gamma, beta, rm=None, rv=None, nbt=None, relu=True,
-                   accumulate=False, eps=1e-5, momentum=0.1):
-    """bn_finalize + bn_apply in one launch, from the folded rows conv2d(..., stats_post=2) accumulated."""
-    lib.ried_bn_apply_train(x.ptr, x.ld, y.ptr, y.ld, x.npix, x.C, _p(stats), nrows, eps, momentum, _p(save), _p(rm),
-                            _p(rv), _p(nbt), _p(gamma), _p(beta), int(relu), int(accumulate), _stream())
+                   accumulate=False, eps=1e-5, momentum=0.1, ldstat: int = 0):
+    """bn_finalize + bn_apply in one launch, from the folded rows conv2d(..., stats_post=2) accumulated.
+    ldstat: channels per statistics row when the layer is a slice of a wider convolution (0: x.C)."""
+    lib.ried_bn_apply_train(x.ptr, x.ld, y.ptr, y.ld, x.npix, x.C, _p(stats), nrows, ldstat, eps, momentum, _p(save),
+                            _p(rm), _p(rv), _p(nbt), _p(gamma), _p(beta), int(relu), int(accumulate), _stream())
 
 
 def conv2d_bn(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, stats, counter, save, rm=None, rv=None,
