@@ -170,6 +170,11 @@ int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ld
                      float* scratch, float* dgamma, float* dbeta, int accumulate, unsigned* counter,
                      ried_stream_t stream);
 long long ried_bn_backward_scratch_floats(int C);
+/* Job-table form: ried_bn_backward for njobs layers that share the pixel count (the sibling 1x1 layers of an
+ * Inception block, src/rinet.py:99-103,225-233) in three launches in all.  jobs: device table, 16 64-bit words per
+ * job: dy, lddy, x, ldx, dx, lddx, C, save, gamma, beta, act, scratch, dgamma, dbeta, accumulate, 0 (meanings as the
+ * arguments of ried_bn_backward; every job its own scratch).  maxC: the largest C among the jobs. */
+int ried_bn_backward_jobs(const long long* jobs, int njobs, long long npix, int maxC, ried_stream_t stream);
 
 /* ---- pooling / upsampling ------------------------------------------------------------------------------------- */
 /* mode 0: MaxPool2d(3,2,1) (src/rinet.py:260,355); 1: MaxPool2d(2,2) (VGG16); 2: avg_pool2d(3,1,1) (:235,330,428) */

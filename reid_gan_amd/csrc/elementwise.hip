@@ -438,7 +438,7 @@ extern "C" int ried_bn_apply_images(const void* x, long long ldx, void* y, long 
 }
 
 // backward pass 1: per-block partial sums[0][c] = sum g, sums[1][c] = sum g*xhat, g = dy * [bn(x) > 0]
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
+__device__ __forceinline__ void bn_bwd_reduce_body(
     const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx, long long npix, int C,
     const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
     float* __restrict__ sums, unsigned* counter, float* __restrict__ fin, float* dgamma, float* dbeta,
@@ -489,8 +489,16 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
     bn_bwd_finish_rows(sums, gridDim.x, C, fin, dgamma, dbeta, accumulate, &red[0][0]);
 }
 
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
+    const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx, long long npix, int C,
+    const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
+    float* __restrict__ sums, unsigned* counter, float* __restrict__ fin, float* dgamma, float* dbeta,
+    int accumulate) {
+  bn_bwd_reduce_body(dy, lddy, x, ldx, npix, C, save, gamma, beta, relu, sums, counter, fin, dgamma, dbeta, accumulate);
+}
+
 // backward pass 2: dx = gamma*invstd*(g - s1/n - xhat*s2/n)
-__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
+__device__ __forceinline__ void bn_bwd_apply_body(
     const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx,
     bf16_t* __restrict__ dx, long long lddx, long long npix, int C, const float* __restrict__ save,
     const float* __restrict__ gamma, const float* __restrict__ beta, int relu, const float* __restrict__ sums) {
@@ -520,10 +528,17 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
   }
 }
 
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
+    const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx,
+    bf16_t* __restrict__ dx, long long lddx, long long npix, int C, const float* __restrict__ save,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, const float* __restrict__ sums) {
+  bn_bwd_apply_body(dy, lddy, x, ldx, dx, lddx, npix, C, save, gamma, beta, relu, sums);
+}
+
 // partial rows [nrows][2][C] -> final sums [2][C] (read by the apply pass) and the parameter gradients
-__global__ __launch_bounds__(ROWRED_THREADS) void bn_bwd_finish_kernel(const float* __restrict__ part, int nrows,
-                                                                       int C, float* __restrict__ fin, float* dgamma,
-                                                                       float* dbeta, int accumulate) {
+__device__ __forceinline__ void bn_bwd_finish_body(const float* __restrict__ part, int nrows, int C,
+                                                   float* __restrict__ fin, float* dgamma, float* dbeta,
+                                                   int accumulate) {
   __shared__ float sh[2][32][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
   float s0, s1;
@@ -537,7 +552,55 @@ __global__ __launch_bounds__(ROWRED_THREADS) void bn_bwd_finish_kernel(const flo
   }
 }
 
+__global__ __launch_bounds__(ROWRED_THREADS) void bn_bwd_finish_kernel(const float* __restrict__ part, int nrows,
+                                                                       int C, float* __restrict__ fin, float* dgamma,
+                                                                       float* dbeta, int accumulate) {
+  bn_bwd_finish_body(part, nrows, C, fin, dgamma, dbeta, accumulate);
+}
+
 #define BN_BWD_MAX_ROWS 1024
+// Job-table form: the BatchNorm backward of several layers that share the pixel count (the sibling 1x1 layers of an
+// Inception block) in three launches instead of three per layer.  A job is 16 64-bit words:
+// dy, lddy, x, ldx, dx, lddx, C, save, gamma, beta, act, scratch, dgamma, dbeta, accumulate, 0  (as ried_bn_backward).
+#define BN_JOB_WORDS 16
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_jobs_kernel(const long long* __restrict__ jobs,
+                                                                        long long npix) {
+  const long long* J = jobs + (long long)blockIdx.y * BN_JOB_WORDS;
+  bn_bwd_reduce_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], npix, (int)J[6], (const float*)J[7],
+                     (const float*)J[8], (const float*)J[9], (int)J[10], (float*)J[11], nullptr, nullptr, nullptr,
+                     nullptr, 0);
+}
+__global__ __launch_bounds__(ROWRED_THREADS) void bn_bwd_finish_jobs_kernel(const long long* __restrict__ jobs,
+                                                                            int nrows) {
+  const long long* J = jobs + (long long)blockIdx.y * BN_JOB_WORDS;
+  const int C = (int)J[6];
+  if ((int)blockIdx.x * 32 >= C) return;
+  float* scratch = (float*)J[11];
+  float* dg = (J[12] && J[13]) ? (float*)J[12] : nullptr;
+  bn_bwd_finish_body(scratch, nrows, C, scratch + (long long)BN_BWD_MAX_ROWS * 2 * C, dg, (float*)J[13], (int)J[14]);
+}
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_jobs_kernel(const long long* __restrict__ jobs,
+                                                                       long long npix) {
+  const long long* J = jobs + (long long)blockIdx.y * BN_JOB_WORDS;
+  const int C = (int)J[6];
+  bn_bwd_apply_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], (bf16_t*)J[4], J[5], npix, C,
+                    (const float*)J[7], (const float*)J[8], (const float*)J[9], (int)J[10],
+                    (const float*)J[11] + (long long)BN_BWD_MAX_ROWS * 2 * C);
+}
+// jobs: device table of njobs records; maxC: the largest channel count among them (sizes the grids)
+extern "C" int ried_bn_backward_jobs(const long long* jobs, int njobs, long long npix, int maxC, hipStream_t stream) {
+  RIED_CHECK_ARG(jobs && njobs > 0 && njobs <= 65535 && npix > 0 && maxC >= 8 && maxC % 8 == 0 && maxC <= 8 * EW_THREADS,
+                 "ried_bn_backward_jobs: bad arguments");
+  const int grid = chan_grid(npix, maxC, 4, BN_BWD_MAX_ROWS);
+  hipLaunchKernelGGL(bn_bwd_reduce_jobs_kernel, dim3(grid, njobs), dim3(EW_THREADS), 0, stream, jobs, npix);
+  hipLaunchKernelGGL(bn_bwd_finish_jobs_kernel, dim3(ceil_div(maxC, 32), njobs), dim3(ROWRED_THREADS), 0, stream, jobs,
+                     grid);
+  hipLaunchKernelGGL(bn_bwd_apply_jobs_kernel, dim3(chan_grid(npix, maxC, 2, 8192), njobs), dim3(EW_THREADS), 0, stream,
+                     jobs, npix);
+  RIED_CHECK_LAUNCH("ried_bn_backward_jobs");
+  return RIED_OK;
+}
+
 // scratch: fp32 [(BN_BWD_MAX_ROWS + 1) * 2 * C] (need not be zeroed).  dgamma/dbeta may be null.
 // counter: null, or one zero-initialised unsigned (left at zero): the reduction's last block then finishes the
 // sums itself instead of a separate launch.

@@ -443,6 +443,7 @@ class ConvBN:
         self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, cin, c.cout, c.kh, c.kw, c.sh, c.sw, deconv)
         self.defer_apply = defer_apply
         self.fused_fwd, self._gstats = None, None      # set by an InputGradGroup that also runs the forward conv
+        self.bn_bwd_grouped = False                    # True: the group runs this layer's BatchNorm backward
         assert not (defer_apply and ctx.grads)
         self.per_image = ctx.per_image and ctx.training
         if self.per_image:     # one (sum, sum of squares) row and one (mean, invstd) pair per image
@@ -520,6 +521,8 @@ class ConvBN:
         """Everything that touches only this layer's own buffers (safe to run beside sibling branches)."""
         ctx, c, st = self.ctx, self.core, self.ctx.st
         draw = self.draw
+        if self.bn_bwd_grouped:      # done for all siblings at once by InputGradGroup.backward()
+            return
         ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
                         ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=self.act,
                         accumulate=self.shared)
@@ -589,18 +592,39 @@ class InputGradGroup:
                 m.fused_fwd = (self, c0)
                 ctx.add_pack(ctx.st.p[m.core.wname], self.wfwd[c0 * cin:], co, 1, 1, cin, cin, 1, 1, 1)
                 c0 += co
+        # the siblings' BatchNorm backward passes as one job table (three launches instead of three per sibling)
+        self.bn_jobs = None
+        if ctx.st is not None and len(self.members) >= 2 and not any(m.bias_key for m in self.members):
+            for m in self.members:
+                m.bn_bwd_grouped = True
+                m._bn_scratch = torch.empty(ops.bn_backward_scratch_floats(m.core.cout), dtype=F32, device=ctx.device)
+            ctx._late.append(self._make_bn_jobs)        # the gradient views have addresses only after finalize()
         return self
+
+    def _make_bn_jobs(self):
+        st = self.ctx.st
+        rows = [ops.bn_backward_job(m.out.g, m.raw, m.draw, m.save, st.p[m.bn + ".weight"], st.p[m.bn + ".bias"],
+                                    m._bn_scratch, st.g[m.bn + ".weight"], st.g[m.bn + ".bias"], act=m.act,
+                                    accumulate=m.shared) for m in self.members]
+        self.bn_jobs = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
+        self.bn_maxc = max(m.core.cout for m in self.members)
+        self.npix = self.drawcat.npix
 
     def forward(self):
         if self.fwd:
             ops.conv2d(self.xin.v, self.wfwd, self.rawcat, 1, 1, 1, 1, 0, 0, stats=self.stats, stats_post=2)
 
     def backward(self):
+        if self.bn_jobs is not None:
+            ops.bn_backward_jobs(self.bn_jobs, len(self.members), self.npix, self.bn_maxc)
         ops.conv2d(self.drawcat, self.wcat, self.xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True)
 
 
+SIBLING_GROUPS = not os.environ.get("RIED_NO_SIBLING_GROUPS")      # switch for A/B runs and tests
+
+
 def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
-    if not ctx.grads:
+    if not ctx.grads or not SIBLING_GROUPS:
         return None
     ctx.dx_group = InputGradGroup(ctx, xin)
     return ctx.dx_group

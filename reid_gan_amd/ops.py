@@ -298,6 +298,17 @@ def bn_backward(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma=
                          int(relu), _p(scratch), _p(dgamma), _p(dbeta), int(accumulate), _p(counter), _stream())
 
 
+def bn_backward_job(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma, dbeta, act=1, accumulate=False):
+    """One 16-word record of the table bn_backward_jobs takes."""
+    return [dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.C, _p(save), _p(gamma), _p(beta), int(act), _p(scratch),
+            _p(dgamma) or 0, _p(dbeta) or 0, int(accumulate), 0]
+
+
+def bn_backward_jobs(table: torch.Tensor, njobs: int, npix: int, maxC: int):
+    """table: int64 device tensor [njobs][16] of bn_backward_job records (layers sharing the pixel count)."""
+    lib.ried_bn_backward_jobs(_p(table), njobs, npix, maxC, _stream())
+
+
 def bn_fold_rows() -> int:
     return lib.ried_bn_fold_rows()
 
