@@ -150,6 +150,11 @@ int ried_bn_apply_train(const void* x, long long ldx, void* y, long long ldy, lo
                         const float* stats, int nrows, int ldstat, float eps, float momentum, float* save,
                         float* running_mean, float* running_var, long long* num_batches_tracked, const float* gamma,
                         const float* beta, int relu, int accumulate, ried_stream_t stream);
+/* Job-table form of ried_bn_apply_train for njobs layers that share the pixel count (one launch): 16 64-bit words
+ * per job: x, ldx, y, ldy, C, stats, nrows, ldstat, save, running_mean, running_var, num_batches_tracked, gamma, beta,
+ * act, accumulate.  maxC / minC: the largest / smallest C among the jobs. */
+int ried_bn_apply_train_jobs(const long long* jobs, int njobs, long long npix, int maxC, int minC, float eps,
+                             float momentum, ried_stream_t stream);
 /* ldstat: channels per statistics row, 0 = C; larger when the layer is a channel slice of a convolution that served
  * several layers at once (stats then points at the slice's first channel: rows [nrows][2][ldstat]). */
 /* Per-image train-mode statistics: the evaluation loop of src/test.py:107-131 feeds one slice at a time, so its

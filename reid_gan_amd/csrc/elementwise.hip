@@ -682,7 +682,7 @@ __device__ __forceinline__ void slice_row_sums(const float* __restrict__ part, i
 
 // y = relu(gamma*(x-mean)*invstd + beta) [+ y], train mode, with the statistics taken from the folded partial rows
 // of the producing conv; the first pixel group of each slice also writes save and the running statistics.
-__global__ __launch_bounds__(EW_THREADS) void bn_apply_train_kernel(
+__device__ __forceinline__ void bn_apply_train_body(
     const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy, long long npix, int C,
     const float* __restrict__ stats, int nrows, int ldstat, float eps, float momentum, float* __restrict__ save,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
@@ -732,6 +732,26 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_train_kernel(
   }
 }
 
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_train_kernel(
+    const bf16_t* __restrict__ x, long long ldx, bf16_t* __restrict__ y, long long ldy, long long npix, int C,
+    const float* __restrict__ stats, int nrows, int ldstat, float eps, float momentum, float* __restrict__ save,
+    float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ nbt,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, int accumulate) {
+  bn_apply_train_body(x, ldx, y, ldy, npix, C, stats, nrows, ldstat, eps, momentum, save, running_mean, running_var,
+                      nbt, gamma, beta, relu, accumulate);
+}
+// Job-table form (blockIdx.z = job): 16 64-bit words per job:
+// x, ldx, y, ldy, C, stats, nrows, ldstat, save, running_mean, running_var, nbt, gamma, beta, act, accumulate
+__global__ __launch_bounds__(EW_THREADS) void bn_apply_train_jobs_kernel(const long long* __restrict__ jobs,
+                                                                         long long npix, float eps, float momentum) {
+  const long long* J = jobs + (long long)blockIdx.z * 16;
+  const int C = (int)J[4];
+  if ((int)blockIdx.y * BN_SLICE >= C) return;
+  bn_apply_train_body((const bf16_t*)J[0], J[1], (bf16_t*)J[2], J[3], npix, C, (const float*)J[5], (int)J[6], (int)J[7],
+                      eps, momentum, (float*)J[8], (float*)J[9], (float*)J[10], (long long*)J[11], (const float*)J[12],
+                      (const float*)J[13], (int)J[14], (int)J[15]);
+}
+
 static inline void slice_grid(long long npix, int C, int iters, int cap, dim3& grid) {
   int ccs = C / 8 < BN_SLICE / 8 ? C / 8 : BN_SLICE / 8;
   int ppb = EW_THREADS / ccs;
@@ -756,6 +776,21 @@ extern "C" int ried_bn_apply_train(const void* x, long long ldx, void* y, long l
                      npix, C, stats, nrows, ldstat, eps, momentum, save, running_mean, running_var, num_batches_tracked,
                      gamma, beta, relu, accumulate);
   RIED_CHECK_LAUNCH("ried_bn_apply_train");
+  return RIED_OK;
+}
+
+// jobs: device table of njobs records (layers sharing npix); maxC / minC: the largest / smallest C among them
+extern "C" int ried_bn_apply_train_jobs(const long long* jobs, int njobs, long long npix, int maxC, int minC, float eps,
+                                        float momentum, hipStream_t stream) {
+  RIED_CHECK_ARG(jobs && njobs > 0 && njobs <= 65535 && npix > 0 && minC >= 8 && maxC >= minC && maxC % 8 == 0,
+                 "ried_bn_apply_train_jobs: bad arguments");
+  dim3 grid, g2;
+  slice_grid(npix, maxC, 2, 8192, grid);
+  slice_grid(npix, minC, 2, 8192, g2);          // fewer channels per pixel: fewer pixels per block pass
+  grid.x = grid.x > g2.x ? grid.x : g2.x;
+  grid.z = njobs;
+  hipLaunchKernelGGL(bn_apply_train_jobs_kernel, grid, dim3(EW_THREADS), 0, stream, jobs, npix, eps, momentum);
+  RIED_CHECK_LAUNCH("ried_bn_apply_train_jobs");
   return RIED_OK;
 }
 

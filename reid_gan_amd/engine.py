@@ -444,6 +444,7 @@ class ConvBN:
         self.defer_apply = defer_apply
         self.fused_fwd, self._gstats = None, None      # set by an InputGradGroup that also runs the forward conv
         self.bn_bwd_grouped = False                    # True: the group runs this layer's BatchNorm backward
+        self.bn_fwd_grouped = False                    # True: the group runs this layer's BatchNorm forward
         assert not (defer_apply and ctx.grads)
         self.per_image = ctx.per_image and ctx.training
         if self.per_image:     # one (sum, sum of squares) row and one (mean, invstd) pair per image
@@ -482,6 +483,8 @@ class ConvBN:
         # A conv bias in front of a train-mode BatchNorm cancels in the normalised output: the conv runs without
         # it and running_mean, the one place it shows, gets momentum * bias afterwards.
         if self.sliced:
+            if self.bn_fwd_grouped:      # normalised with its siblings by InputGradGroup.forward()
+                return
             stats, rows, ldstat = self.stats, self.stat_rows, 0
             if self.fused_fwd is not None:       # the sibling group's one convolution has produced raw and the sums
                 grp, c0 = self.fused_fwd
@@ -592,6 +595,12 @@ class InputGradGroup:
                 m.fused_fwd = (self, c0)
                 ctx.add_pack(ctx.st.p[m.core.wname], self.wfwd[c0 * cin:], co, 1, 1, cin, cin, 1, 1, 1)
                 c0 += co
+            # the BatchNorm forward of the siblings that do not add onto the block's output: one job table
+            self.fwd_jobs = None
+            if FWD_BN_JOBS and sum(not m.accumulate for m in self.members) >= 2:
+                for m in self.members:
+                    m.bn_fwd_grouped = not m.accumulate
+                ctx._late.append(self._make_fwd_jobs)
         # the siblings' BatchNorm backward passes as one job table (three launches instead of three per sibling)
         self.bn_jobs = None
         if ctx.st is not None and len(self.members) >= 2 and not any(m.bias_key for m in self.members):
@@ -610,9 +619,24 @@ class InputGradGroup:
         self.bn_maxc = max(m.core.cout for m in self.members)
         self.npix = self.drawcat.npix
 
+    def _make_fwd_jobs(self):
+        st, rows, c0, cs = self.ctx.st, [], 0, []
+        for m in self.members:
+            if m.bn_fwd_grouped:
+                rows.append(ops.bn_apply_train_job(
+                    m.raw, m.out.v, self.stats.data_ptr() + 4 * c0, self.stat_rows, self.total, m.save,
+                    st.b[m.bn + ".running_mean"], st.b[m.bn + ".running_var"], st.b[m.bn + ".num_batches_tracked"],
+                    st.p[m.bn + ".weight"], st.p[m.bn + ".bias"], act=m.act))
+                cs.append(m.core.cout)
+            c0 += m.core.cout
+        self.fwd_jobs = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
+        self.fwd_c = (len(rows), max(cs), min(cs))
+
     def forward(self):
         if self.fwd:
             ops.conv2d(self.xin.v, self.wfwd, self.rawcat, 1, 1, 1, 1, 0, 0, stats=self.stats, stats_post=2)
+            if self.fwd_jobs is not None:
+                ops.bn_apply_train_jobs(self.fwd_jobs, self.fwd_c[0], self.rawcat.npix, self.fwd_c[1], self.fwd_c[2])
 
     def backward(self):
         if self.bn_jobs is not None:
@@ -621,6 +645,7 @@ class InputGradGroup:
 
 
 SIBLING_GROUPS = not os.environ.get("RIED_NO_SIBLING_GROUPS")      # switch for A/B runs and tests
+FWD_BN_JOBS = not os.environ.get("RIED_NO_FWD_BN_JOBS")
 
 
 def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:

@@ -309,6 +309,17 @@ def bn_backward_jobs(table: torch.Tensor, njobs: int, npix: int, maxC: int):
     lib.ried_bn_backward_jobs(_p(table), njobs, npix, maxC, _stream())
 
 
+def bn_apply_train_job(x: View, y: View, stats_ptr: int, nrows, ldstat, save, rm, rv, nbt, gamma, beta, act=1,
+                       accumulate=False):
+    """One 16-word record of the table bn_apply_train_jobs takes."""
+    return [x.ptr, x.ld, y.ptr, y.ld, x.C, stats_ptr, nrows, ldstat, _p(save), _p(rm), _p(rv), _p(nbt), _p(gamma),
+            _p(beta), int(act), int(accumulate)]
+
+
+def bn_apply_train_jobs(table: torch.Tensor, njobs: int, npix: int, maxC: int, minC: int, eps=1e-5, momentum=0.1):
+    lib.ried_bn_apply_train_jobs(_p(table), njobs, npix, maxC, minC, eps, momentum, _stream())
+
+
 def bn_fold_rows() -> int:
     return lib.ried_bn_fold_rows()
 

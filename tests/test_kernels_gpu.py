@@ -566,6 +566,44 @@ def test_bn_small_layer_kernels(C, cin, H):
     close(from_view(yv), from_view(y3), 1e-2, "y vs three-launch")
 
 
+def test_bn_apply_train_job_table_matches_the_per_layer_launches():
+    """Sibling layers as channel slices of one wide 1x1 convolution: the job-table BatchNorm forward gives, bit for
+    bit, what one bn_apply_train per layer gives (outputs, save, running statistics, batch counter)."""
+    N, H, cin, widths, acts = 8, 8, 64, (128, 32, 16, 48), (0, 1, 1, 2)
+    total = sum(widths)
+    x = (r(N, cin, H, H, seed=40) * 0.7).to(torch.bfloat16).float()
+    wp = (r(total, 1, 1, cin, seed=41) * 0.2).to(torch.bfloat16).to(DEV)
+    raw = ops.new_view(N, H, H, total)
+    nrows = min(ops.bn_fold_rows(), ops.conv2d_stat_rows(N, H, H, cin, total, 1, 1))
+    stats = torch.zeros(ops.bn_fold_rows() * 2 * total, device=DEV)
+    ops.conv2d(to_view(x), wp, raw, 1, 1, 1, 1, 0, 0, stats=stats, stats_post=2)
+
+    def state(C, seed):
+        return dict(save=torch.full((2 * C,), float("nan"), device=DEV), rm=(r(C, seed=seed) * 0.1).to(DEV),
+                    rv=(r(C, seed=seed + 1).abs() + 0.5).to(DEV), nbt=torch.full((), 3, dtype=torch.long, device=DEV),
+                    gamma=(r(C, seed=seed + 2) + 1.0).to(DEV), beta=(r(C, seed=seed + 3) * 0.3).to(DEV))
+
+    outs, rows, c0 = [], [], 0
+    for i, (C, act) in enumerate(zip(widths, acts)):
+        a, b = state(C, 50 + 10 * i), state(C, 50 + 10 * i)
+        ya, yb = ops.new_view(N, H, H, C), ops.new_view(N, H, H, C)
+        xs = raw.slice(c0, c0 + C)
+        ops.bn_apply_train(xs, ya, stats[c0:], nrows, a["save"], a["gamma"], a["beta"], a["rm"], a["rv"], a["nbt"],
+                           relu=act, ldstat=total)
+        rows.append(ops.bn_apply_train_job(xs, yb, stats.data_ptr() + 4 * c0, nrows, total, b["save"], b["rm"], b["rv"],
+                                           b["nbt"], b["gamma"], b["beta"], act=act))
+        outs.append((a, b, ya, yb))
+        c0 += C
+    table = torch.tensor(rows, dtype=torch.int64).to(DEV)
+    ops.bn_apply_train_jobs(table, len(rows), N * H * H, max(widths), min(widths))
+    torch.cuda.synchronize()
+    for a, b, ya, yb in outs:
+        assert torch.equal(ya.torch(), yb.torch())
+        for k in ("save", "rm", "rv", "nbt"):
+            assert torch.equal(a[k], b[k]), k
+        assert b["nbt"].item() == 4 and not torch.isnan(b["save"]).any()
+
+
 @pytest.mark.parametrize("n,d,C", [(256, 32, 256), (64, 64, 512)])
 def test_attention_scores_softmax(n, d, C):
     """softmax_j(q_i . k_j) in one pass (src/rinet.py:171-174) against torch on the bf16-rounded q, k."""
