@@ -432,7 +432,7 @@ class ConvBN:
         self.bias_key = conv_key + ".bias" if bias else None
         self.act, self.shared = act, shared
         grp = ctx.dx_group
-        grouped = (grp is not None and ctx.grads and need_dx and not deconv and grp.wants(xin, k, stride, pad))
+        grouped = grp is not None and ctx.grads and need_dx and grp.wants(xin, k, stride, pad)
         self.core = ConvCore(ctx, conv_key + ".weight", cin, cout, k, stride, pad, deconv, xin,
                              need_dx and not grouped, wgrad_out=wgrad_out)
         c = self.core
@@ -578,7 +578,8 @@ class InputGradGroup:
             co = m.core.cout
             m.draw = self.drawcat.slice(c0, c0 + co)
             if ctx.st is not None:      # master (Cout, Cin, 1, 1) -> column slice [c0, c0 + Cout) of row c_in
-                ctx.add_pack(ctx.st.p[m.core.wname], self.wcat[c0:], cin, 1, 1, co, 1, 1, 1, cin, dst_pitch=total)
+                rs, cs = (co, 1) if m.core.deconv else (1, cin)     # (a 1x1 transposed conv's master is (Cin, Cout, 1, 1))
+                ctx.add_pack(ctx.st.p[m.core.wname], self.wcat[c0:], cin, 1, 1, co, rs, 1, 1, cs, dst_pitch=total)
             c0 += co
         self.fwd = (ctx.st is not None and ctx.training and not ctx.per_image and len(self.members) >= 2 and
                     all(m.sliced and not m.bias_key for m in self.members))
@@ -593,7 +594,8 @@ class InputGradGroup:
                 co = m.core.cout
                 m.raw = self.rawcat.slice(c0, c0 + co)
                 m.fused_fwd = (self, c0)
-                ctx.add_pack(ctx.st.p[m.core.wname], self.wfwd[c0 * cin:], co, 1, 1, cin, cin, 1, 1, 1)
+                rs, cs = (1, co) if m.core.deconv else (cin, 1)
+                ctx.add_pack(ctx.st.p[m.core.wname], self.wfwd[c0 * cin:], co, 1, 1, cin, rs, 1, 1, cs)
                 c0 += co
             # the BatchNorm forward of the siblings that do not add onto the block's output: one job table
             self.fwd_jobs = None
@@ -969,7 +971,7 @@ def _grid_tail(ctx, s, prefix, xin: Slot, out_slice: Slot, cin, cs, decoder):
 def inception_b(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
     """src/rinet.py:254-291: cat(64 | 64 | maxpool(cin) or sample(128))."""
     k = 4 if decoder else 3
-    grp = None if decoder else open_input_grad_group(ctx, xin)     # (decoder blocks start with 1x1 transposed convs)
+    grp = open_input_grad_group(ctx, xin)      # (decoder blocks: the siblings are 1x1 transposed convolutions)
     with _Lane(ctx, 0) as b0:
         _chain(ctx, b0, prefix, [("branch3x3dbl_1", cin, 32, 1, 1, 0), ("branch3x3dbl_2", 32, 48, 3, 1, 1),
                                  ("branch3x3dbl_3", 48, 64, k, 2, 1)], xin, out.sub(64, 128), deconv=decoder)
@@ -987,7 +989,7 @@ def inception_b(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
 def inception_d(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
     """src/rinet.py:349-387: cat(128 | 128 | maxpool(cin) or sample(256))."""
     k = 4 if decoder else 3
-    grp = None if decoder else open_input_grad_group(ctx, xin)     # (decoder blocks start with 1x1 transposed convs)
+    grp = open_input_grad_group(ctx, xin)      # (decoder blocks: the siblings are 1x1 transposed convolutions)
     with _Lane(ctx, 0) as b0:
         _chain(ctx, b0, prefix, [("branch7x7x3_1", cin, 128, 1, 1, 0), ("branch7x7x3_2", 128, 128, (1, 7), 1, (0, 3)),
                                  ("branch7x7x3_3", 128, 128, (7, 1), 1, (3, 0)),
