@@ -129,10 +129,12 @@ int ried_pack_weight(const float* src, void* dst, int N, int R, int S, int C, lo
 /* ---- BatchNorm2d, train mode (src/rinet.py:187,199; eps 1e-5, momentum 0.1) ------------------------------------ */
 /* stats [nrows][2][C] (partial sum, sum sq rows; count values per channel in all) -> save [2][C] (mean, invstd);
  * updates running stats (unbiased variance) and num_batches_tracked when given.  fold: NULL, or fp32 scratch
- * [ried_bn_finalize_fold_floats(C)] that lets very many rows (512x512 inference) be reduced in two wide steps. */
-int ried_bn_finalize(const float* stats, int nrows, int C, long long count, float eps, float momentum, float* save,
-                     float* running_mean, float* running_var, long long* num_batches_tracked, float* fold,
-                     ried_stream_t stream);
+ * [ried_bn_finalize_fold_floats(C)] that lets very many rows (512x512 inference) be reduced in two wide steps.
+ * ldstat: channels per statistics row when the layer is a channel slice of a wider convolution (stats then points at
+ * the slice's first channel; 0: C). */
+int ried_bn_finalize(const float* stats, int nrows, int C, int ldstat, long long count, float eps, float momentum,
+                     float* save, float* running_mean, float* running_var, long long* num_batches_tracked,
+                     float* fold, ried_stream_t stream);
 long long ried_bn_finalize_fold_floats(int C);
 int ried_bn_eval_stats(const float* running_mean, const float* running_var, int C, float eps, float* save,
                        ried_stream_t stream);

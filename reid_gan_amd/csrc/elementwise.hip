@@ -231,13 +231,14 @@ extern "C" int ried_wgrad_reduce_jobs(const long long* jobs, const int* blockmap
 // lanes, four rows in flight per lane.  Returns (sum, sum2) for channel c in the threads with ty == 0.
 #define ROWRED_THREADS 1024
 __device__ __forceinline__ void reduce_rows_2c(const float* __restrict__ part, int nrows, int C, int c, int ty,
-                                               float& s0, float& s1, float (*sh)[32][32]) {
+                                               float& s0, float& s1, float (*sh)[32][32], int ldp = 0) {
   float a = 0.f, b = 0.f;
+  if (ldp <= 0) ldp = C;          // channels per row of the buffer (C: the layer owns the whole rows)
   if (c < C) {
 #pragma unroll 4
     for (int r = ty; r < nrows; r += 32) {
-      a += part[(long long)r * 2 * C + c];
-      b += part[(long long)r * 2 * C + C + c];
+      a += part[(long long)r * 2 * ldp + c];
+      b += part[(long long)r * 2 * ldp + ldp + c];
     }
   }
   sh[0][ty][threadIdx.x & 31] = a;
@@ -252,13 +253,13 @@ __device__ __forceinline__ void reduce_rows_2c(const float* __restrict__ part, i
 
 // stats: [nrows][2][C] per-block partial sum / sum of squares from the conv epilogue.  save: [2][C] mean, invstd.
 __global__ __launch_bounds__(ROWRED_THREADS) void bn_finalize_kernel(
-    const float* __restrict__ stats, int nrows, int C, float count, float eps, float momentum,
+    const float* __restrict__ stats, int nrows, int C, int ldstat, float count, float eps, float momentum,
     float* __restrict__ save, float* __restrict__ running_mean, float* __restrict__ running_var,
     long long* __restrict__ nbt) {
   __shared__ float sh[2][32][32];
   const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
   float s0, s1;
-  reduce_rows_2c(stats, nrows, C, c, ty, s0, s1, sh);
+  reduce_rows_2c(stats, nrows, C, c, ty, s0, s1, sh, ldstat);
   if (ty == 0 && c < C) {
     float mean = s0 / count;
     float var = fmaxf(s1 / count - mean * mean, 0.f);
@@ -276,32 +277,38 @@ __global__ __launch_bounds__(ROWRED_THREADS) void bn_finalize_kernel(
 // fold[r'][j] = sum over rows r = r' (mod FOLD_ROWS) of stats[r][j], j < 2C: with tens of thousands of partial
 // rows (512x512 inference) one block per 32 channels would crawl through them alone.
 #define FOLD_ROWS 256
-__global__ __launch_bounds__(256) void rows_fold_kernel(const float* __restrict__ stats, int nrows, int W2,
+__global__ __launch_bounds__(256) void rows_fold_kernel(const float* __restrict__ stats, int nrows, int C, int ldstat,
                                                         float* __restrict__ fold) {
   const int j = blockIdx.x * 256 + threadIdx.x, rp = blockIdx.y;
-  if (j >= W2) return;
+  if (j >= 2 * C) return;
+  const int k = j >= C;
+  const float* src = stats + k * ldstat + (j - k * C);       // column j of the layer's [2][C] slice of a row
   float a = 0.f;
 #pragma unroll 4
-  for (int r = rp; r < nrows; r += FOLD_ROWS) a += stats[(long long)r * W2 + j];
-  fold[(long long)rp * W2 + j] = a;
+  for (int r = rp; r < nrows; r += FOLD_ROWS) a += src[(long long)r * 2 * ldstat];
+  fold[(long long)rp * 2 * C + j] = a;
 }
 
 // fold: NULL, or fp32 scratch [ried_bn_finalize_fold_floats(C)]; with it, more than 4 * FOLD_ROWS partial rows are
 // first folded down to FOLD_ROWS by a wide kernel.
 extern "C" long long ried_bn_finalize_fold_floats(int C) { return (long long)FOLD_ROWS * 2 * C; }
 
-extern "C" int ried_bn_finalize(const float* stats, int nrows, int C, long long count, float eps, float momentum,
-                                float* save, float* running_mean, float* running_var,
+// ldstat: channels per statistics row when the layer is a channel slice of a wider convolution (0: C).
+extern "C" int ried_bn_finalize(const float* stats, int nrows, int C, int ldstat, long long count, float eps,
+                                float momentum, float* save, float* running_mean, float* running_var,
                                 long long* num_batches_tracked, float* fold, hipStream_t stream) {
   RIED_CHECK_ARG(stats && save && C > 0 && count > 0 && nrows > 0, "ried_bn_finalize: bad arguments");
+  if (ldstat <= 0) ldstat = C;
+  RIED_CHECK_ARG(ldstat >= C, "ried_bn_finalize: ldstat smaller than C");
   if (fold && nrows > 4 * FOLD_ROWS) {
     hipLaunchKernelGGL(rows_fold_kernel, dim3(ceil_div(2 * C, 256), FOLD_ROWS), dim3(256), 0, stream, stats, nrows,
-                       2 * C, fold);
+                       C, ldstat, fold);
     stats = fold;
     nrows = FOLD_ROWS;
+    ldstat = C;
   }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(C, 32)), dim3(ROWRED_THREADS), 0, stream, stats, nrows, C,
-                     (float)count, eps, momentum, save, running_mean, running_var, num_batches_tracked);
+                     ldstat, (float)count, eps, momentum, save, running_mean, running_var, num_batches_tracked);
   RIED_CHECK_LAUNCH("ried_bn_finalize");
   return RIED_OK;
 }

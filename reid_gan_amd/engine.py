@@ -433,6 +433,8 @@ class ConvBN:
         self.act, self.shared = act, shared
         grp = ctx.dx_group
         grouped = grp is not None and ctx.grads and need_dx and grp.wants(xin, k, stride, pad)
+        fwd_member = (grp is not None and not ctx.grads and not defer_apply and not bias
+                      and grp.wants(xin, k, stride, pad))      # forward-only plans: the group shares the convolution
         self.core = ConvCore(ctx, conv_key + ".weight", cin, cout, k, stride, pad, deconv, xin,
                              need_dx and not grouped, wgrad_out=wgrad_out)
         c = self.core
@@ -459,6 +461,8 @@ class ConvBN:
         self.fold = (torch.empty(ops.bn_finalize_fold_floats(cout), dtype=F32, device=ctx.device)
                      if self.stat_rows > 1024 else None)
         self.draw: Optional[View] = None
+        if fwd_member:
+            grp.join(self)
         if ctx.grads:
             ctx.need_f32(ops.bn_backward_scratch_floats(cout))
             if bias:
@@ -501,10 +505,17 @@ class ConvBN:
                 ops.axpy_f32(st.b[self.bn + ".running_mean"], st.p[self.bias_key], 0.1)
             return
         if ctx.training:
-            c.conv(self.raw, stats=self.stats)
-            ops.bn_finalize(self.stats, self.stat_rows, c.cout, self.raw.npix, self.save,
-                            st.b[self.bn + ".running_mean"],
-                            st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"], fold=self.fold)
+            stats, rows, ldstat = self.stats, self.stat_rows, 0
+            if self.fused_fwd is not None:       # raw and the partial sums are channel slices of the sibling group's
+                grp, c0 = self.fused_fwd
+                if self._gstats is None:
+                    self._gstats = grp.stats[c0:]
+                stats, rows, ldstat = self._gstats, grp.stat_rows, grp.total
+            else:
+                c.conv(self.raw, stats=self.stats)
+            ops.bn_finalize(stats, rows, c.cout, self.raw.npix, self.save, st.b[self.bn + ".running_mean"],
+                            st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"], fold=self.fold,
+                            ldstat=ldstat)
             if self.bias_key:
                 ops.axpy_f32(st.b[self.bn + ".running_mean"], st.p[self.bias_key], 0.1)
         else:
@@ -568,13 +579,14 @@ class InputGradGroup:
         backward weights; returns the layer to put FIRST in the block's sequence (it runs last in backward)."""
         ctx = self.ctx
         ctx.dx_group = None
-        assert len(self.members) >= 1
         N, H, W, cin = self.xin.shape
         total = sum(m.core.cout for m in self.members)
-        self.drawcat = ops.new_view(N, H, W, total, ctx.device)
-        self.wcat = torch.empty(cin * total, dtype=torch.bfloat16, device=ctx.device)     # [cin][total]
         c0 = 0
-        for m in self.members:
+        if ctx.grads:
+            assert len(self.members) >= 1
+            self.drawcat = ops.new_view(N, H, W, total, ctx.device)
+            self.wcat = torch.empty(cin * total, dtype=torch.bfloat16, device=ctx.device)     # [cin][total]
+        for m in self.members if ctx.grads else ():
             co = m.core.cout
             m.draw = self.drawcat.slice(c0, c0 + co)
             if ctx.st is not None:      # master (Cout, Cin, 1, 1) -> column slice [c0, c0 + Cout) of row c_in
@@ -582,13 +594,23 @@ class InputGradGroup:
                 ctx.add_pack(ctx.st.p[m.core.wname], self.wcat[c0:], cin, 1, 1, co, rs, 1, 1, cs, dst_pitch=total)
             c0 += co
         self.fwd = (ctx.st is not None and ctx.training and not ctx.per_image and len(self.members) >= 2 and
-                    all(m.sliced and not m.bias_key for m in self.members))
+                    not any(m.bias_key or m.defer_apply or m.per_image for m in self.members))
+        self.folded = self.fwd and all(m.sliced for m in self.members)
+        self.fwd_jobs = None
         if self.fwd:
             self.total = total
             self.rawcat = ops.new_view(N, H, W, total, ctx.device)
             self.wfwd = torch.empty(total * cin, dtype=torch.bfloat16, device=ctx.device)           # [total][cin]
-            self.stat_rows = min(ops.conv2d_stat_rows(N, H, W, cin, total, 1, 1), ops.bn_fold_rows())
-            ctx.stats(self, "stats", ops.bn_fold_rows() * 2 * total, zeroed=True)
+            self.stat_rows = ops.conv2d_stat_rows(N, H, W, cin, total, 1, 1)
+            if self.folded:    # small layers: atomically folded rows, finished inside the siblings' apply kernels
+                self.stat_rows = min(self.stat_rows, ops.bn_fold_rows())
+                ctx.stats(self, "stats", ops.bn_fold_rows() * 2 * total, zeroed=True)
+            else:              # one row per tile; every sibling finalizes its channel slice of them
+                ctx.stats(self, "stats", self.stat_rows * 2 * total)
+                for m in self.members:
+                    m.sliced = False
+                    if self.stat_rows > 1024 and m.fold is None:
+                        m.fold = torch.empty(ops.bn_finalize_fold_floats(m.core.cout), dtype=F32, device=ctx.device)
             c0 = 0
             for m in self.members:
                 co = m.core.cout
@@ -598,14 +620,13 @@ class InputGradGroup:
                 ctx.add_pack(ctx.st.p[m.core.wname], self.wfwd[c0 * cin:], co, 1, 1, cin, rs, 1, 1, cs)
                 c0 += co
             # the BatchNorm forward of the siblings that do not add onto the block's output: one job table
-            self.fwd_jobs = None
-            if FWD_BN_JOBS and sum(not m.accumulate for m in self.members) >= 2:
+            if self.folded and FWD_BN_JOBS and sum(not m.accumulate for m in self.members) >= 2:
                 for m in self.members:
                     m.bn_fwd_grouped = not m.accumulate
                 ctx._late.append(self._make_fwd_jobs)
         # the siblings' BatchNorm backward passes as one job table (three launches instead of three per sibling)
         self.bn_jobs = None
-        if ctx.st is not None and len(self.members) >= 2 and not any(m.bias_key for m in self.members):
+        if ctx.grads and ctx.st is not None and len(self.members) >= 2 and not any(m.bias_key for m in self.members):
             for m in self.members:
                 m.bn_bwd_grouped = True
                 m._bn_scratch = torch.empty(ops.bn_backward_scratch_floats(m.core.cout), dtype=F32, device=ctx.device)
@@ -636,11 +657,14 @@ class InputGradGroup:
 
     def forward(self):
         if self.fwd:
-            ops.conv2d(self.xin.v, self.wfwd, self.rawcat, 1, 1, 1, 1, 0, 0, stats=self.stats, stats_post=2)
+            ops.conv2d(self.xin.v, self.wfwd, self.rawcat, 1, 1, 1, 1, 0, 0, stats=self.stats,
+                       stats_post=2 if self.folded else 0)
             if self.fwd_jobs is not None:
                 ops.bn_apply_train_jobs(self.fwd_jobs, self.fwd_c[0], self.rawcat.npix, self.fwd_c[1], self.fwd_c[2])
 
     def backward(self):
+        if not self.ctx.grads:
+            return
         if self.bn_jobs is not None:
             ops.bn_backward_jobs(self.bn_jobs, len(self.members), self.npix, self.bn_maxc)
         ops.conv2d(self.drawcat, self.wcat, self.xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True)
@@ -651,7 +675,7 @@ FWD_BN_JOBS = not os.environ.get("RIED_NO_FWD_BN_JOBS")
 
 
 def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
-    if not ctx.grads or not SIBLING_GROUPS:
+    if not SIBLING_GROUPS or not (ctx.grads or (ctx.training and not ctx.per_image and ctx.st is not None)):
         return None
     ctx.dx_group = InputGradGroup(ctx, xin)
     return ctx.dx_group
@@ -659,7 +683,9 @@ def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
 
 def close_input_grad_group(grp: Optional[InputGradGroup], seq: "Seq"):
     if grp is not None:
-        seq.layers.insert(0, grp.close())
+        grp.close()
+        if grp.ctx.grads or grp.fwd:
+            seq.layers.insert(0, grp)
 
 
 class ConvBNC1:

@@ -262,9 +262,11 @@ def bn_finalize_fold_floats(C) -> int:
     return lib.ried_bn_finalize_fold_floats(C)
 
 
-def bn_finalize(stats, nrows, C, count, save, rm=None, rv=None, nbt=None, eps=1e-5, momentum=0.1, fold=None):
-    lib.ried_bn_finalize(_p(stats), nrows, C, count, eps, momentum, _p(save), _p(rm), _p(rv), _p(nbt), _p(fold),
-                         _stream())
+def bn_finalize(stats, nrows, C, count, save, rm=None, rv=None, nbt=None, eps=1e-5, momentum=0.1, fold=None,
+                ldstat: int = 0):
+    """ldstat: channels per statistics row when the layer is a slice of a wider convolution (0: C)."""
+    lib.ried_bn_finalize(_p(stats), nrows, C, ldstat, count, eps, momentum, _p(save), _p(rm), _p(rv), _p(nbt),
+                         _p(fold), _stream())
 
 
 def bn_eval_stats(rm, rv, C, save, eps=1e-5):

@@ -126,6 +126,49 @@ def test_generator_forward_backward_vs_oracle_and_golden(golden_dir):
         grad_close(st.g[k].cpu(), grads[k], k, cos=0.95, ratio=0.08)
 
 
+@pytest.mark.parametrize("grads", [True, False])
+def test_sibling_groups_on_the_large_map_path(golden_dir, monkeypatch, grads):
+    """Folded statistics off: every layer takes the path of large maps (one statistics row per convolution tile), where
+    a sibling group's members finalize their channel slice of the shared rows (ried_bn_finalize with ldstat) - in the
+    training plan and in the forward-only plan.  Against the golden output and against the same plan without groups."""
+    monkeypatch.setattr(engine, "BN_FOLD", False)
+    sliced_calls = []
+    real = ops.bn_finalize
+
+    def counting(*a, **kw):
+        if kw.get("ldstat", 0) > 0:
+            sliced_calls.append(kw["ldstat"])
+        return real(*a, **kw)
+    monkeypatch.setattr(ops, "bn_finalize", counting)
+    sd = g_state()
+    x, _ = synth_batch(2, 64, seed=7)
+    dout = (torch.randn(2, 1, 64, 64, generator=torch.Generator().manual_seed(5)) * 1e-3).to(DEV)
+
+    def run():
+        st = engine.State(sd, DEV)
+        G = engine.Generator(st, 2, 64, 64, grads=grads)
+        out = G.forward(x.to(DEV)).cpu().clone()
+        if grads:
+            st.zero_grad()
+            G.backward(dout)
+        torch.cuda.synchronize()
+        return out, st
+    out, st = run()
+    assert len(sliced_calls) >= 20, "no sibling group took the tile-row path"
+    gold = np.load(os.path.join(golden_dir, "rigan_train_64.npz"))
+    act_close(out, torch.from_numpy(gold["out"]), "out vs golden", mx=2e-2, mean=5e-3)
+    monkeypatch.setattr(engine, "SIBLING_GROUPS", False)
+    n = len(sliced_calls)
+    out2, st2 = run()
+    assert len(sliced_calls) == n
+    act_close(out, out2, "grouped vs ungrouped", mx=1e-2, mean=2e-3)
+    for k in st.b:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert torch.allclose(st.b[k], st2.b[k], rtol=2e-2, atol=2e-3), k
+    if grads:
+        grad_close(st.flat_grad.cpu(), st2.flat_grad.cpu(), "gradients grouped vs ungrouped", cos=0.999, ratio=0.02)
+
+
 def test_generator_eval_mode_and_batch_one(golden_dir):
     sd = g_state()
     x, _ = synth_batch(2, 64, seed=7)
@@ -433,3 +476,27 @@ def test_inference_metrics_vs_oracle():
     for i in range(B):
         for a, b in zip(got[i][1], res[i][1]):
             assert abs(a - b) <= 2e-2 * abs(b), (got[i][1], res[i][1])
+
+
+def test_inference_at_the_benchmark_size_with_and_without_sibling_groups(monkeypatch):
+    """Batch 32 of 512 x 512 (the inference workload of the benchmark): the sibling groups' shared convolutions write
+    thousands of statistics rows there, which every member reduces in two steps from its channel slice.  The
+    prediction and the per-slice metrics must equal the plan without groups up to bf16 rounding of the shared
+    convolution's different tile order."""
+    sd = g_state()
+    B, H = 32, 512
+    x, y = synth_batch(B, H, seed=78)
+    xd, yd = x.to(DEV), y.to(DEV)
+    a = InferenceEngine(sd, B, H, H)
+    pa, sa = a.run(xd, yd)
+    pa, ma = pa.cpu().clone(), a.measures(sa)
+    del a
+    monkeypatch.setattr(engine, "SIBLING_GROUPS", False)
+    b = InferenceEngine(sd, B, H, H)
+    pb, sb = b.run(xd, yd)
+    pb, mb = pb.cpu(), b.measures(sb)
+    assert torch.isfinite(pa).all()
+    act_close(pa, pb, "grouped vs ungrouped prediction", mx=1e-2, mean=1e-3)
+    for i in range(B):
+        for u, v in zip(ma[i][1], mb[i][1]):
+            assert abs(u - v) <= 5e-3 * abs(v) + 1e-5, (i, ma[i], mb[i])

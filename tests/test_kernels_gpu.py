@@ -294,6 +294,29 @@ def test_bn_finalize_folds_many_rows():
     close(a[0].cpu(), stats[:, 0].sum(0).cpu() / rows, 1e-5, "mean")
 
 
+@pytest.mark.parametrize("rows", [37, 5000])
+def test_bn_finalize_on_a_channel_slice_of_wider_rows(rows):
+    """A layer that is a channel slice of a wider convolution (ldstat): same statistics and running statistics as on
+    a compact copy of its columns, directly and through the two-step reduction, bit for bit."""
+    g = torch.Generator().manual_seed(4)
+    total, c0, C = 208, 128, 48
+    wide = torch.rand(rows, 2, total, generator=g).to(DEV)
+    wide[:, 1] += 1.0
+    compact = wide[:, :, c0:c0 + C].contiguous()
+    for use_fold in (False, True):
+        res = []
+        for stats, ld in ((compact, 0), (wide.view(-1)[c0:], total)):
+            save = torch.full((2, C), float("nan"), device=DEV)
+            rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            nbt = torch.zeros((), dtype=torch.long, device=DEV)
+            fold = torch.full((ops.bn_finalize_fold_floats(C),), float("nan"), device=DEV) if use_fold else None
+            ops.bn_finalize(stats, rows, C, rows, save, rm, rv, nbt, fold=fold, ldstat=ld)
+            res.append((save, rm, rv, nbt))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        assert not torch.isnan(res[1][0]).any() and res[1][3].item() == 1
+
+
 def test_conv2d_bias_act_slice_accumulate():
     x = r(2, 64, 8, 8, seed=3)
     w = r(128, 64, 3, 3, seed=4, scale=0.05)
