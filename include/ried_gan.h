@@ -163,9 +163,10 @@ int ried_bn_apply_train_jobs(const long long* jobs, int njobs, long long npix, i
  * BatchNorm layers normalise every slice on its own.  stats: [nimg * rows_per_img][2][C] partial rows, the rows of an
  * image consecutive (rows_per_img = 1 after ried_conv2d with stats_post = 3); count = pixels per image;
  * save [nimg][2][C] = (mean, 1/sqrt(var + eps)).  ried_bn_apply_images = ried_bn_apply with that per-image save on
- * views of nimg images of npix_per_img pixels.  Running statistics are not touched. */
-int ried_bn_finalize_images(const float* stats, int rows_per_img, int nimg, int C, long long count, float eps,
-                            float* save, ried_stream_t stream);
+ * views of nimg images of npix_per_img pixels.  Running statistics are not touched.  ldstat: channels per statistics
+ * row when the layer is a channel slice of a wider convolution (0: C). */
+int ried_bn_finalize_images(const float* stats, int rows_per_img, int nimg, int C, int ldstat, long long count,
+                            float eps, float* save, ried_stream_t stream);
 int ried_bn_apply_images(const void* x, long long ldx, void* y, long long ldy, long long npix_per_img, int nimg, int C,
                          const float* save, const float* gamma, const float* beta, int relu, int accumulate,
                          ried_stream_t stream);

@@ -410,23 +410,26 @@ extern "C" int ried_bn_apply(const void* x, long long ldx, void* y, long long ld
 // stats: [nimg * rows_per_img][2][C] partial (sum, sum of squares) rows, the rows of an image consecutive
 // (rows_per_img = 1: what ried_conv2d leaves with stats_post = 3)  ->  save [nimg][2][C] = (mean, 1/sqrt(var+eps)).
 __global__ void bn_finalize_images_kernel(const float* __restrict__ stats, int rows_per_img, int nimg, int C,
-                                          float count, float eps, float* __restrict__ save) {
+                                          int ldstat, float count, float eps, float* __restrict__ save) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nimg * C) return;
   const int n = i / C, c = i - n * C;
-  const float* p = stats + (long long)n * rows_per_img * 2 * C + c;
+  const float* p = stats + (long long)n * rows_per_img * 2 * ldstat + c;
   float s0 = 0.f, s1 = 0.f;
-  for (int r = 0; r < rows_per_img; ++r) { s0 += p[(long long)r * 2 * C]; s1 += p[(long long)r * 2 * C + C]; }
+  for (int r = 0; r < rows_per_img; ++r) { s0 += p[(long long)r * 2 * ldstat]; s1 += p[(long long)r * 2 * ldstat + ldstat]; }
   const float mean = s0 / count;
   const float var = fmaxf(s1 / count - mean * mean, 0.f);
   save[(long long)n * 2 * C + c] = mean;
   save[(long long)n * 2 * C + C + c] = rsqrtf(var + eps);
 }
-extern "C" int ried_bn_finalize_images(const float* stats, int rows_per_img, int nimg, int C, long long count,
-                                       float eps, float* save, hipStream_t stream) {
+// ldstat: channels per statistics row when the layer is a channel slice of a wider convolution (0: C).
+extern "C" int ried_bn_finalize_images(const float* stats, int rows_per_img, int nimg, int C, int ldstat,
+                                       long long count, float eps, float* save, hipStream_t stream) {
   RIED_CHECK_ARG(stats && save && rows_per_img > 0 && nimg > 0 && C > 0 && count > 0, "ried_bn_finalize_images: bad arguments");
+  if (ldstat <= 0) ldstat = C;
+  RIED_CHECK_ARG(ldstat >= C, "ried_bn_finalize_images: ldstat smaller than C");
   hipLaunchKernelGGL(bn_finalize_images_kernel, dim3(ceil_div((long long)nimg * C, 256)), dim3(256), 0, stream, stats,
-                     rows_per_img, nimg, C, (float)count, eps, save);
+                     rows_per_img, nimg, C, ldstat, (float)count, eps, save);
   RIED_CHECK_LAUNCH("ried_bn_finalize_images");
   return RIED_OK;
 }

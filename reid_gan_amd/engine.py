@@ -478,8 +478,14 @@ class ConvBN:
     def forward(self):
         ctx, c, st = self.ctx, self.core, self.ctx.st
         if self.per_image:
-            c.conv(self.raw, stats=self.img_stats, stats_post=3)
-            ops.bn_finalize_images(self.img_stats, 1, c.N, c.cout, c.Ho * c.Wo, self.img_save)
+            if self.fused_fwd is not None:       # raw and the per-image sums are channel slices of the sibling group's
+                grp, c0 = self.fused_fwd
+                if self._gstats is None:
+                    self._gstats = grp.stats[c0:]
+                ops.bn_finalize_images(self._gstats, 1, c.N, c.cout, c.Ho * c.Wo, self.img_save, ldstat=grp.total)
+            else:
+                c.conv(self.raw, stats=self.img_stats, stats_post=3)
+                ops.bn_finalize_images(self.img_stats, 1, c.N, c.cout, c.Ho * c.Wo, self.img_save)
             if not self.defer_apply:
                 ops.bn_apply_images(self.raw, self.out.v, self.img_save, st.p[self.bn + ".weight"],
                                     st.p[self.bn + ".bias"], relu=self.act, accumulate=self.accumulate)
@@ -593,16 +599,19 @@ class InputGradGroup:
                 rs, cs = (co, 1) if m.core.deconv else (1, cin)     # (a 1x1 transposed conv's master is (Cin, Cout, 1, 1))
                 ctx.add_pack(ctx.st.p[m.core.wname], self.wcat[c0:], cin, 1, 1, co, rs, 1, 1, cs, dst_pitch=total)
             c0 += co
-        self.fwd = (ctx.st is not None and ctx.training and not ctx.per_image and len(self.members) >= 2 and
-                    not any(m.bias_key or m.defer_apply or m.per_image for m in self.members))
-        self.folded = self.fwd and all(m.sliced for m in self.members)
+        self.fwd = (ctx.st is not None and ctx.training and len(self.members) >= 2 and
+                    not any(m.bias_key or m.defer_apply for m in self.members))
+        self.images = self.fwd and ctx.per_image          # one statistics row per image
+        self.folded = self.fwd and not self.images and all(m.sliced for m in self.members)
         self.fwd_jobs = None
         if self.fwd:
             self.total = total
             self.rawcat = ops.new_view(N, H, W, total, ctx.device)
             self.wfwd = torch.empty(total * cin, dtype=torch.bfloat16, device=ctx.device)           # [total][cin]
             self.stat_rows = ops.conv2d_stat_rows(N, H, W, cin, total, 1, 1)
-            if self.folded:    # small layers: atomically folded rows, finished inside the siblings' apply kernels
+            if self.images:
+                ctx.stats(self, "stats", N * 2 * total, zeroed=True)
+            elif self.folded:  # small layers: atomically folded rows, finished inside the siblings' apply kernels
                 self.stat_rows = min(self.stat_rows, ops.bn_fold_rows())
                 ctx.stats(self, "stats", ops.bn_fold_rows() * 2 * total, zeroed=True)
             else:              # one row per tile; every sibling finalizes its channel slice of them
@@ -658,7 +667,7 @@ class InputGradGroup:
     def forward(self):
         if self.fwd:
             ops.conv2d(self.xin.v, self.wfwd, self.rawcat, 1, 1, 1, 1, 0, 0, stats=self.stats,
-                       stats_post=2 if self.folded else 0)
+                       stats_post=3 if self.images else 2 if self.folded else 0)
             if self.fwd_jobs is not None:
                 ops.bn_apply_train_jobs(self.fwd_jobs, self.fwd_c[0], self.rawcat.npix, self.fwd_c[1], self.fwd_c[2])
 
@@ -675,7 +684,7 @@ FWD_BN_JOBS = not os.environ.get("RIED_NO_FWD_BN_JOBS")
 
 
 def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
-    if not SIBLING_GROUPS or not (ctx.grads or (ctx.training and not ctx.per_image and ctx.st is not None)):
+    if not SIBLING_GROUPS or not (ctx.grads or (ctx.training and ctx.st is not None)):
         return None
     ctx.dx_group = InputGradGroup(ctx, xin)
     return ctx.dx_group

@@ -281,9 +281,10 @@ def bn_apply(x: View, y: View, save, gamma, beta, relu=True, accumulate=False):
                       int(accumulate), _stream())
 
 
-def bn_finalize_images(stats, rows_per_img: int, nimg: int, C: int, count: int, save, eps=1e-5):
-    """Per-image (mean, invstd) [nimg][2][C] from partial rows [nimg * rows_per_img][2][C]."""
-    lib.ried_bn_finalize_images(_p(stats), rows_per_img, nimg, C, count, eps, _p(save), _stream())
+def bn_finalize_images(stats, rows_per_img: int, nimg: int, C: int, count: int, save, eps=1e-5, ldstat: int = 0):
+    """Per-image (mean, invstd) [nimg][2][C] from partial rows [nimg * rows_per_img][2][C] (ldstat: channels per row
+    when the layer is a channel slice of a wider convolution's rows)."""
+    lib.ried_bn_finalize_images(_p(stats), rows_per_img, nimg, C, ldstat, count, eps, _p(save), _stream())
 
 
 def bn_apply_images(x: View, y: View, save, gamma, beta, relu=True, accumulate=False):
