@@ -388,34 +388,57 @@ def main():
     from reid_gan_amd import dp
     from reid_gan_amd.synth import synth_batch
     from reid_gan_amd.train_step import TrainStep
-    rank, local, world = dp.init_from_env("nccl")
+    if os.environ.get("RIED_HANG_DUMP"):      # debugging aid: every thread's stack after that many seconds, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RIED_HANG_DUMP"]), exit=True)
+    # RIED_DP_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks (ranks then share cards;
+    # RCCL itself refuses two ranks on one device)
+    backend = os.environ.get("RIED_DP_BACKEND", "nccl")
+    if backend != "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    rank, local, world = dp.init_from_env(backend)
+    force_pg = world == 1 and bool(os.environ.get("RIED_FORCE_PG"))      # one-rank group: the multi-rank code path
+    if force_pg:
+        import torch.distributed as dist0
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist0.init_process_group(backend=backend, rank=0, world_size=1)
     if world != args.gpus:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local if backend == "nccl" else local % torch.cuda.device_count())
     import torch.distributed as dist
-    pg = dist.group.WORLD if world > 1 else None
+    pg = dist.group.WORLD if (world > 1 or force_pg) else None
+    multi = pg is not None
 
     g, d, vgg = synth_states()
     ts = TrainStep(g, d, vgg, args.batch, args.size, args.size, lr=1e-4, use_graph=not args.no_graph,
                    process_group=pg)
+    if os.environ.get("RIED_HANG_DUMP"):
+        import threading
+
+        def watch():
+            while True:
+                time.sleep(10)
+                print(f"[rank {rank}] steps done {ts.steps_done}, segment {ts.segment}", file=sys.stderr, flush=True)
+        threading.Thread(target=watch, daemon=True).start()
     x, y = synth_batch(args.batch, args.size, seed=1234 + rank)
     ts.x.copy_(x.cuda())
     ts.y.copy_(y.cuda())
     for _ in range(args.warmup):
         ts.step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         ts.step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -455,7 +478,7 @@ def main():
                                         for k, v in fam.items()}}
     else:
         ts._run_eager()       # keep the collectives of the instrumented step matched on every rank
-    if world > 1:
+    if multi:
         dist.barrier()
     if rank == 0:
         if world == 1 and not args.no_infer:
@@ -469,7 +492,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

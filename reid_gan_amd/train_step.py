@@ -79,6 +79,7 @@ class TrainStep:
         self.overlap_gbwd = not os.environ.get("RIED_NO_OVERLAP_GBWD")
         self.graphs = None          # [(graph, tensor to all-reduce after it or None)]
         self.steps_done = 0
+        self.segment = -1
 
     # ------------------------------------------------------------------ collectives
     def _allreduce_mean(self, t: torch.Tensor):
@@ -198,7 +199,8 @@ class TrainStep:
         else:
             if self.graphs is None:
                 self._capture()
-            for g, t in self.graphs:
+            for i, (g, t) in enumerate(self.graphs):
+                self.segment = i          # (where a stuck rank stands: read by watchdogs)
                 g.replay()
                 if t is not None:
                     self._allreduce_mean(t)
