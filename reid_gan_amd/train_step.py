@@ -82,12 +82,14 @@ class TrainStep:
         self.segment = -1
 
     # ------------------------------------------------------------------ collectives
-    def _allreduce_mean(self, t: torch.Tensor):
+    def _allreduce_mean(self, t):
+        """t: a tensor, or a tuple of tensors exchanged at the same point of the step."""
         if self.pg is not None:
             import torch.distributed as dist
-            dist.all_reduce(t, group=self.pg)
-            if self.world > 1:
-                t.mul_(1.0 / self.world)
+            for u in (t if isinstance(t, tuple) else (t,)):
+                dist.all_reduce(u, group=self.pg)
+                if self.world > 1:
+                    u.mul_(1.0 / self.world)
 
     # ------------------------------------------------------------------ the step
     # The step is written as a generator that yields the tensors to average across ranks.  With one rank the
@@ -137,10 +139,9 @@ class TrainStep:
             self.gs.zero_grad()
             self.G.backward(self.dpred)
             self._join(side)
-        yield self.ds.flat_grad
+        # (the generator's gradients are complete here too in the last iteration: one exchange point for both)
+        yield (self.ds.flat_grad, self.gs.flat_grad) if last else self.ds.flat_grad
         self.ds.adam(4.0 * self.lr)
-        if last:
-            yield self.gs.flat_grad
 
     def _g_loss_backward(self, n: int):
         B, H, W, sc = self.B, self.H, self.W, self.sc

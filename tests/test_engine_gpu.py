@@ -343,6 +343,17 @@ def test_train_step_at_128_patches():
     act_close(ts.G.out.cpu(), ref["pred"], "pred", mx=2e-2, mean=5e-3)
 
 
+def weights_agree(a, b):
+    """Two runs of the same two steps.  The few float atomics left in the step (loss sums) differ in the last bit
+    between runs, and Adam's first updates are lr * sign(gradient)-like: a weight whose gradient is almost zero can
+    move the other way (up to 2 * lr per step apart: lr 1e-4 for G, 4e-4 for D).  So: nearly all weights agree
+    tightly, and none is further apart than those sign flips allow."""
+    for st_a, st_b, lr in ((a.gs, b.gs, 1e-4), (a.ds, b.ds, 4e-4)):
+        d = (st_a.flat - st_b.flat).abs()
+        assert (d > 3 * lr).float().mean().item() <= 1e-4, (lr, d.max().item())
+        assert d.max().item() <= 2 * 2 * lr * 1.05, (lr, d.max().item())
+
+
 def test_segmented_graphs_equal_single_graph(monkeypatch):
     """With several ranks the step is captured as graph segments split at the collectives (and the side streams
     must rejoin before each split).  Here the collectives are stubbed out (identical replicas: the mean over ranks
@@ -362,8 +373,7 @@ def test_segmented_graphs_equal_single_graph(monkeypatch):
     a, b = one.losses(), seg.losses()
     for k in a:
         assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
-    assert torch.allclose(one.gs.flat, seg.gs.flat, rtol=0, atol=3e-4)
-    assert torch.allclose(one.ds.flat, seg.ds.flat, rtol=0, atol=1.2e-3)
+    weights_agree(one, seg)
 
 
 def test_train_step_through_a_one_rank_rccl_group(monkeypatch):
@@ -389,8 +399,7 @@ def test_train_step_through_a_one_rank_rccl_group(monkeypatch):
         a, b = one.losses(), par.losses()
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
-        assert torch.allclose(one.gs.flat, par.gs.flat, rtol=0, atol=3e-4)
-        assert torch.allclose(one.ds.flat, par.ds.flat, rtol=0, atol=1.2e-3)
+        weights_agree(one, par)
     finally:
         dist.destroy_process_group()
 
