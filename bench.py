@@ -123,7 +123,7 @@ def instrumented_step(ts):
     return fam
 
 
-def cpu_baseline(budget_s=20.0):
+def cpu_baseline(budget_s=12.0):
     from oracle import ried_oracle as O
     from reid_gan_amd.synth import synth_batch
     cores = os.cpu_count() or 1
@@ -134,7 +134,7 @@ def cpu_baseline(budget_s=20.0):
     st = O.TrainState(g, d, vgg)
     O.train_step(st, x, y)                       # warm-up
     t0, n = time.perf_counter(), 0
-    while n < 20 and (time.perf_counter() - t0 < budget_s or n < 2):
+    while n < 400 and (time.perf_counter() - t0 < budget_s or n < 2):
         O.train_step(st, x, y)
         n += 1
     dt = time.perf_counter() - t0
