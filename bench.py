@@ -419,7 +419,8 @@ def main():
         def watch():
             while True:
                 time.sleep(10)
-                print(f"[rank {rank}] steps done {ts.steps_done}, segment {ts.segment}", file=sys.stderr, flush=True)
+                print(f"[rank {rank}] steps done {ts.steps_done}, segment {ts.segment}, exchange {ts.exchange}",
+                      file=sys.stderr, flush=True)
         threading.Thread(target=watch, daemon=True).start()
     x, y = synth_batch(args.batch, args.size, seed=1234 + rank)
     ts.x.copy_(x.cuda())

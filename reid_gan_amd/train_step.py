@@ -80,6 +80,7 @@ class TrainStep:
         self.graphs = None          # [(graph, tensor to all-reduce after it or None)]
         self.steps_done = 0
         self.segment = -1
+        self.exchange = (0, 0)
 
     # ------------------------------------------------------------------ collectives
     def _allreduce_mean(self, t):
@@ -87,6 +88,7 @@ class TrainStep:
         if self.pg is not None:
             import torch.distributed as dist
             for u in (t if isinstance(t, tuple) else (t,)):
+                self.exchange = (self.exchange[0] + 1, u.numel())      # (count, size of the one in flight)
                 dist.all_reduce(u, group=self.pg)
                 if self.world > 1:
                     u.mul_(1.0 / self.world)
