@@ -254,7 +254,7 @@ N_LANES = 4
 # depend on the order in which the conv's blocks finish, so two runs differ in the last bits.  BN_FOLD = False
 # (or RIED_DETERMINISTIC=1) keeps every reduction in a fixed order: runs are then bit-reproducible.
 BN_FOLD = not os.environ.get("RIED_DETERMINISTIC")
-BN_FOLD_MAX_ELEMS = int(os.environ.get("RIED_BN_FOLD_MAX_ELEMS", 4 << 20))
+BN_FOLD_MAX_ELEMS = int(os.environ.get("RIED_BN_FOLD_MAX_ELEMS", 16 << 20))
 PAR_BRANCHES = True      # False: Par runs its branches one after another on the caller's stream (whole plans are
                          # then the unit of concurrency: see train_step.SliceInference)
 _side_streams: List["torch.cuda.Stream"] = []
