@@ -60,13 +60,15 @@ def get_patch(full_input_img: torch.Tensor, full_target_img: torch.Tensor, patch
 class ct_dataset:
     """src/loader.py:7-57 with the slices resident on the device.  load_mode 0 (lazy reads in the reference) and
     1 (all in memory) both load everything here: the point of this class is that pixel data never returns to the
-    host.  transform must be None (the reference's train.py passes None unless --transform is set)."""
+    host.  transform is tested for truth as the reference does (`if self.transform:`, src/loader.py:46): None and
+    False - the default of train.py's --transform flag (src/train.py:41,64) - mean no transform; a true value would
+    be a host callable on numpy arrays, which the device-resident pipeline does not run."""
 
     def __init__(self, mode, load_mode, saved_path, test_patient, patch_n=None, patch_size=None, transform=None,
                  device="cuda"):
         assert mode in ['train', 'test'], "mode is 'train' or 'test'"
         assert load_mode in [0, 1], "load_mode is 0 or 1"
-        if transform is not None:
+        if transform:
             raise NotImplementedError("ct_dataset on the device takes no host transform")
         input_path = sorted(glob(os.path.join(saved_path, '*_input.npy')))
         target_path = sorted(glob(os.path.join(saved_path, '*_target.npy')))

@@ -343,6 +343,59 @@ def test_train_step_at_128_patches():
     act_close(ts.G.out.cpu(), ref["pred"], "pred", mx=2e-2, mean=5e-3)
 
 
+def test_train_step_at_the_benchmark_batch():
+    """Batch 128 of 64 x 64 (BASELINE configs[1], what bench.py times): the plan picks other convolution tiles,
+    BatchNorm statistics folding, split-K factors and grouped weight-gradient shapes than at batch 4.  Against the
+    oracle with bf16 storage emulated.  With 128 patches every BatchNorm layer averages over >= 2048 samples, so the
+    generator is far less chaotic than at batch 2-4 and EVERY gradient tensor is held to cosine >= 0.95."""
+    B, H = 128, 64
+    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
+    x, y = synth_batch(B, H, seed=1234)
+    ost = O.TrainState(gsd, dsd, vgg, lr=1e-4)
+    with emu():
+        ref = O.train_step(ost, x, y, want_grads=True)
+    ts = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+    ts.step(x.to(DEV), y.to(DEV))
+    got = ts.losses()
+    for k in ("dloss1", "dloss2", "gloss", "vgg", "dssim", "gen"):
+        assert abs(got[k] - ref[k]) <= 2e-2 * abs(ref[k]) + 1e-4, (k, got[k], ref[k])
+    act_close(ts.G.out.cpu(), ref["pred"], "pred", mx=2e-2, mean=5e-3)
+    grad_close(ts.dpred.cpu(), ref["dpred"], "d gloss / d pred", cos=0.99, ratio=0.03)
+    for k, g in ref["d_grads_1"].items():
+        if not k.endswith("key_conv.bias"):
+            grad_close(ts.ds.g[k].cpu(), g, "D " + k, cos=0.98, ratio=0.08)
+    bad = []
+    for k, g in ref["g_grads"].items():
+        try:
+            grad_close(ts.gs.g[k].cpu(), g, "G " + k, cos=0.95, ratio=0.15)
+        except AssertionError as e:
+            bad.append(str(e))
+    assert not bad, (len(bad), bad[:12])
+
+
+def test_inference_at_the_benchmark_size_vs_oracle():
+    """Batch 32 of 512 x 512 (BASELINE configs[2], what bench.py times) against the oracle's fp32 forward of the
+    whole batch and its restatement of compute_measure on every slice."""
+    sd = g_state()
+    B, H = 32, 512
+    x, y = synth_batch(B, H, seed=78)
+    eng = InferenceEngine(sd, B, H, H)
+    pred, sums = eng.run(x.to(DEV), y.to(DEV))
+    p, got = pred.cpu().clone(), eng.measures(sums)
+    del eng
+    for i in (0, 13, 31):      # the metric kernel on the device prediction: fp32 both sides
+        xi, yi, pi = [O.trunc(t[i, 0]) for t in (x, y, p)]
+        o, q = O.compute_measure(xi, yi, pi, 400.0)
+        for a, b in zip(got[i][0] + got[i][1], o + q):
+            assert abs(a - b) <= 2e-4 * abs(b) + 2e-5, (i, got[i], o, q)
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    pref, res, _ = O.infer_slice(sd, x, y)
+    act_close(p, pref, "pred", mx=2e-2, mean=5e-3)
+    for i in range(B):
+        for a, b in zip(got[i][1], res[i][1]):
+            assert abs(a - b) <= 2e-2 * abs(b), (i, got[i][1], res[i][1])
+
+
 def weights_agree(a, b):
     """Two runs of the same two steps.  The few float atomics left in the step (loss sums) differ in the last bit
     between runs, and Adam's first updates are lr * sign(gradient)-like: a weight whose gradient is almost zero can

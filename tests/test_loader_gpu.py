@@ -28,7 +28,7 @@ def test_loader_matches_reference(golden_dir, tmp_path):
     write_slice_files(str(tmp_path), ["L019", "L064", "L150"], 3, 96, 96, seed=50)
     np.random.seed(777)
     dl = L.get_loader(mode="train", load_mode=1, saved_path=str(tmp_path), test_patient="L064", patch_n=4,
-                      patch_size=32, transform=None, batch_size=4, num_workers=0)
+                      patch_size=32, transform=False, batch_size=4, num_workers=0)    # False: src/train.py:41,64
     assert len(dl.dataset) == 6 and len(dl) == 2
     batches = list(dl)
     assert len(batches) == int(g["train_batches"][0])

@@ -72,6 +72,7 @@ def test_discriminator_module_against_golden(golden_dir):
     ("inception_d_enc", lambda: rinet.InceptionD(256, None), 256, 8, 310),
     ("snconv_64_128_s2", lambda: rinet.SNConv2d(64, 128, 3, 2, padding=1), 64, 8, 313),
     ("self_attn_256", lambda: rinet.Self_Attn(256), 256, 8, 314),
+    ("self_attn_512", lambda: rinet.Self_Attn(512), 512, 4, 315),
 ])
 def test_block_modules_against_golden(golden_dir, name, ctor, cin, hw, seed):
     m = _load(ctor(), seed).cuda()
