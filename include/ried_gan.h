@@ -206,6 +206,14 @@ int ried_ew(int op, const void* a, long long lda, const void* y, long long ldy, 
 /* out[c] += sum_p a[p][c]; scratch: fp32 [ried_colsum_scratch_floats(C)] */
 int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, float* scratch, ried_stream_t stream);
 long long ried_colsum_scratch_floats(int C);
+/* ried_colsum without a workspace argument.  No counterpart in the reference: it is for callers that cannot
+ * allocate device memory - code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  The
+ * partial rows live in a 1 MiB device array built into the library (one copy per GPU, held until the process ends);
+ * the call allocates and frees nothing.  C <= 1024; a larger C is refused with an error.  Same kernels and grid as
+ * ried_colsum (results equal up to the order of that kernel's fp32 LDS atomics).  All calls on one GPU share that
+ * array: calls that may overlap on one GPU (different streams, different threads) race; serialise them.  The first
+ * call on a device resolves the array's address (hipGetSymbolAddress); make it outside stream capture. */
+int ried_colsum_static(const void* a, long long lda, long long npix, int C, float* out, ried_stream_t stream);
 /* out[0] += scale * sum a*b (b NULL: sum a) */
 int ried_dot(const void* a, long long lda, const void* b, long long ldb, long long npix, int C, float scale, float* out,
              ried_stream_t stream);

@@ -1372,6 +1372,46 @@ extern "C" int ried_colsum(const void* a, long long lda, long long npix, int C, 
 }
 extern "C" long long ried_colsum_scratch_floats(int C) { return (long long)COLSUM_MAX_ROWS * C; }
 
+// ried_colsum for callers that cannot allocate or pass a workspace (HIP graph capture, serving loops): the partial
+// rows live in a file-scope device array instead of a caller buffer.  Each GPU holds its own copy of the array at
+// its own address; the host-side name below is only a handle for hipGetSymbolAddress, never a kernel argument.
+#define COLSUM_STATIC_MAX_C 1024
+#define COLSUM_STATIC_MAX_DEVICES 64
+static __device__ __align__(256) float colsum_static_scratch[COLSUM_MAX_ROWS * COLSUM_STATIC_MAX_C];   // 1 MiB per GPU
+static float* colsum_static_ptr[COLSUM_STATIC_MAX_DEVICES];      // device address of the array, per device ordinal
+
+extern "C" int ried_colsum_static(const void* a, long long lda, long long npix, int C, float* out,
+                                  hipStream_t stream) {
+  CHECK_VIEW("ried_colsum_static", a, lda, C);
+  RIED_CHECK_ARG(out && npix > 0, "ried_colsum_static: bad arguments");
+  RIED_CHECK_ARG(C <= COLSUM_STATIC_MAX_C, "ried_colsum_static: C = %d exceeds the built-in scratch (C <= %d); use "
+                 "ried_colsum with a caller workspace", C, COLSUM_STATIC_MAX_C);
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= COLSUM_STATIC_MAX_DEVICES) {
+    ried_set_error("ried_colsum_static: hipGetDevice: %s (device %d)", hipGetErrorString(e), dev);
+    return RIED_ERR_HIP;
+  }
+  float* scratch = __atomic_load_n(&colsum_static_ptr[dev], __ATOMIC_ACQUIRE);
+  if (!scratch) {      // first call on this device (racing threads resolve the same address)
+    e = hipGetSymbolAddress((void**)&scratch, HIP_SYMBOL(colsum_static_scratch));
+    if (e != hipSuccess || !scratch) {
+      ried_set_error("ried_colsum_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+      return RIED_ERR_HIP;
+    }
+    __atomic_store_n(&colsum_static_ptr[dev], scratch, __ATOMIC_RELEASE);
+  }
+  // same grid and kernels as ried_colsum: rows [0, grid) of the scratch are fully overwritten for channels [0, C)
+  // before the second kernel reads them, so what an earlier call left behind is never read
+  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, COLSUM_MAX_ROWS);
+  if (grid * EW_THREADS < C / 8) grid = ceil_div(C / 8, EW_THREADS);
+  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(EW_THREADS), C * sizeof(float), stream, (const bf16_t*)a, lda,
+                     npix, C, scratch);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, stream, scratch, grid, C, out);
+  RIED_CHECK_LAUNCH("ried_colsum_static");
+  return RIED_OK;
+}
+
 // ---------------------------------------------------------------------------
 // softmax over the last dimension (reference: src/rinet.py:174) and its backward
 // ---------------------------------------------------------------------------
