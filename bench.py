@@ -440,7 +440,7 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
     losses = ts.losses()

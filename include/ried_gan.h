@@ -299,6 +299,11 @@ int ried_gloss_scalars(float* sc, float wv, float ws, float wg, ried_stream_t st
  * do_clamp folds trunc() of src/test.py:77-80.  gmap (two-image form): fp32 [3][nimg][H][W] for ried_ssim_bwd. */
 int ried_ssim_fwd(const float* a, const float* b, const float* ref, int nimg, int H, int W, float c1, float c2,
                   int do_clamp, float lo, float hi, float* sums, float* gmap, ried_stream_t stream);
+/* gaussian(11, 1.5) of src/loss.py:24-26 / src/measure.py:77-79 as the caller's torch computes it: g_host = 11 fp32
+ * weights in host memory, used by every later ried_ssim_fwd / ried_ssim_bwd call of the process.  Without this call
+ * the library normalises the eleven taps with a left-to-right fp32 sum, which differs from torch's sum in the last
+ * bit; on raw HU the SSIM value is sensitive to that bit (see csrc/ssim.hip). */
+int ried_ssim_set_window(const float* g_host, int n);
 /* da (+)= scale * scale_dev[0] * d(sum ssim_map)/d a */
 int ried_ssim_bwd(const float* a, const float* ref, const float* gmap, int nimg, int H, int W, float scale,
                   const float* scale_dev, float* da, int accumulate, ried_stream_t stream);

@@ -70,9 +70,22 @@ class _Lib:
                               ctypes.c_longlong if ret == "long long" else ctypes.c_int)
                 fn.argtypes = [_ctype_of(t) for t, _ in args]
             self._dll = dll
+            self._set_ssim_window(dll)
             if os.environ.get("RIED_FORCE_TILE"):      # tuning hook, e.g. "0,0,-1" (see ried_conv2d_force_tile)
                 dll.ried_conv2d_force_tile(*[int(v) for v in os.environ["RIED_FORCE_TILE"].split(",")])
         return self._dll
+
+    @staticmethod
+    def _set_ssim_window(dll):
+        """The SSIM kernels get the Gaussian window exactly as the reference builds it (src/loss.py:24-26: a torch
+        fp32 tensor divided by its torch sum), bit for bit: on raw HU the loss value depends on the last bit of
+        the weights' sum."""
+        import torch
+        from math import exp
+        g = torch.Tensor([exp(-(x - 11 // 2) ** 2 / float(2 * 1.5 ** 2)) for x in range(11)])
+        g = (g / g.sum()).contiguous()
+        if dll.ried_ssim_set_window(ctypes.c_void_p(g.data_ptr()), 11) != 0:
+            raise RuntimeError("ried_ssim_set_window failed")
 
     def call(self, name: str, *args):
         dll = self.load()

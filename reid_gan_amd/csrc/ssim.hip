@@ -7,6 +7,15 @@
 // (horizontal pass into LDS, vertical pass in registers), forms the SSIM quotient with the same
 // sigma = E[x^2] - mu^2 algebra and reduces with wavefront shuffles.  fp32 throughout: the
 // variance cancellation on raw HU makes bf16 unusable here.
+//
+// Conditioning.  On a nearly constant region at -1000 HU, E[x^2] ~ 1e6 and sigma^2 ~ 1: evaluated as written,
+// fp32 keeps one digit (the reference's own fp32 result is 0.08 from its fp64 result at noise sd 0.5).  The
+// kernels evaluate the SAME expression on values shifted by a per-tile constant c (the tile's first pixel):
+//   mu = mu' + c S,  E[x^2] - mu^2 = (E'[(x-c)^2] - mu'^2) + (1 - S)(2 c mu' + c^2 S)
+// where primes are the filtered shifted values and S = the sum of the 121 fp32 window weights (1 - S ~ 1e-8: the
+// reference's window does not sum to one exactly, which gives its sigma^2 a bias of c^2 (1 - S) that is kept
+// here).  This is an identity in exact arithmetic, so the result is the reference expression's exact value up to
+// fp32 round-off of O(1) quantities, in every input regime.
 // With three images (x, pred, y) one pass yields both metric triples of measure.compute_measure
 // from a single read of each image: 12 bytes per pixel.
 #include "common.h"
@@ -18,7 +27,15 @@
 #define TP (TIN + 1)        // row pitch of the input tiles of the forward kernel (43: odd)
 #define TPL (TIN * TP)      // one input plane
 
-struct SsimWindow { float g[11]; };
+struct SsimWindow { float g[11]; float S, dS; };    // S = sum of the 2-d window's fp32 weights, dS = 1 - S
+
+static void finish_window(SsimWindow& w) {
+  double S = 0.0;       // the reference's 2-d window is the fp32 outer product of the 1-d one (src/loss.py:30)
+  for (int i = 0; i < 11; ++i)
+    for (int j = 0; j < 11; ++j) S += (double)(float)(w.g[i] * w.g[j]);
+  w.S = (float)S;
+  w.dS = (float)(1.0 - S);
+}
 
 static SsimWindow make_window() {
   // built as the reference builds it: exp() in double per tap, stored fp32, normalised in fp32
@@ -26,7 +43,23 @@ static SsimWindow make_window() {
   float s = 0.f;
   for (int i = 0; i < 11; ++i) { w.g[i] = (float)exp(-(double)((i - 5) * (i - 5)) / (2.0 * 1.5 * 1.5)); s += w.g[i]; }
   for (int i = 0; i < 11; ++i) w.g[i] = w.g[i] / s;
+  finish_window(w);
   return w;
+}
+
+// The window in use.  The default normalises with a left-to-right fp32 sum; torch's sum of the same eleven floats
+// differs from it in the last bit, which moves every weight by up to 3e-8 and 1 - S from +8e-8 to -7e-8 - and on raw
+// HU that is visible: c^2 (1 - S) is +-0.08 at c = -1000.  A caller that wants the reference's numbers passes the
+// weights its torch produces (ried_ssim_set_window); the Python binding does so when it loads the library.
+static SsimWindow g_window = make_window();
+
+extern "C" int ried_ssim_set_window(const float* g_host, int n) {
+  RIED_CHECK_ARG(g_host && n == 11, "ried_ssim_set_window: the kernels take an 11-tap window");
+  SsimWindow w;
+  for (int i = 0; i < 11; ++i) w.g[i] = g_host[i];
+  finish_window(w);
+  g_window = w;
+  return RIED_OK;
 }
 
 __device__ __forceinline__ float clampf(float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); }
@@ -57,6 +90,12 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
   const int tx = tile % tiles_x, ty = tile / tiles_x;
   const int x0 = tx * TS - HALO, y0 = ty * TS - HALO;
   if (tile != blockIdx.x * tpb) __syncthreads();        // the previous tile's LDS planes have been read
+  float cs[NIMG];                                       // shift constants: the tile's first pixel (always inside)
+#pragma unroll
+  for (int k = 0; k < NIMG; ++k) {
+    float t = imgs[k][ibase + (long long)(ty * TS) * W + tx * TS];
+    cs[k] = do_clamp ? clampf(t, lo, hi) : t;
+  }
 
   {
     // every global load of the halo tile is issued before the first LDS store, so that the block pays the
@@ -74,7 +113,7 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
       for (int k = 0; k < NIMG; ++k) {
         float t = imgs[k][off];
         if (do_clamp) t = clampf(t, lo, hi);
-        v[j][k] = ok ? t : 0.f;
+        v[j][k] = (ok ? t : 0.f) - cs[k];       // zero padding, then the shift
       }
     }
 #pragma unroll
@@ -156,14 +195,18 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
       float q[NQ];
 #pragma unroll
       for (int k = 0; k < NQ; ++k) q[k] = q4[k][j];
+      const float S = win.S, dS = win.dS;
       if constexpr (NIMG == 2) {
-        float mu1 = q[0], mu2 = q[1];
+        const float ca = cs[0], cr = cs[1];
+        float mu1 = q[0] + ca * S, mu2 = q[1] + cr * S;
         float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-        float s1 = q[2] - mu1s, s2 = q[3] - mu2s, s12 = q[4] - mu12;
+        float s1 = (q[2] - q[0] * q[0]) + dS * (2.f * ca * q[0] + ca * ca * S);
+        float s2 = (q[3] - q[1] * q[1]) + dS * (2.f * cr * q[1] + cr * cr * S);
+        float s12 = (q[4] - q[0] * q[1]) + dS * (ca * q[1] + cr * q[0] + ca * cr * S);
         float A1 = 2.f * mu12 + c1, A2 = 2.f * s12 + c2, B1 = mu1s + mu2s + c1, B2 = s1 + s2 + c2;
         float ssim = (A1 * A2) / (B1 * B2);
         s_ssim_a += ssim;
-        float a = tin[(yy + HALO) * TP + xx + HALO], r = tin[TPL + (yy + HALO) * TP + xx + HALO];
+        float a = tin[(yy + HALO) * TP + xx + HALO] + ca, r = tin[TPL + (yy + HALO) * TP + xx + HALO] + cr;
         s_mse_a += (a - r) * (a - r);
         if (gmap) {
           float ib1b2 = 1.f / (B1 * B2);
@@ -174,20 +217,23 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
           gmap[2 * plane + o] = 2.f * A1 * ib1b2;
         }
       } else {
-        float mua = q[0], mub = q[1], mur = q[2];
-        float murs = mur * mur, sr = q[5] - murs;
+        const float ca = cs[0], cb = cs[1], cr = cs[2];
+        float mua = q[0] + ca * S, mub = q[1] + cb * S, mur = q[2] + cr * S;
+        float murs = mur * mur, sr = (q[5] - q[2] * q[2]) + dS * (2.f * cr * q[2] + cr * cr * S);
         {
           float m1s = mua * mua, m12 = mua * mur;
-          float s1 = q[3] - m1s, s12 = q[6] - m12;
+          float s1 = (q[3] - q[0] * q[0]) + dS * (2.f * ca * q[0] + ca * ca * S);
+          float s12 = (q[6] - q[0] * q[2]) + dS * (ca * q[2] + cr * q[0] + ca * cr * S);
           s_ssim_a += ((2.f * m12 + c1) * (2.f * s12 + c2)) / ((m1s + murs + c1) * (s1 + sr + c2));
         }
         {
           float m1s = mub * mub, m12 = mub * mur;
-          float s1 = q[4] - m1s, s12 = q[7] - m12;
+          float s1 = (q[4] - q[1] * q[1]) + dS * (2.f * cb * q[1] + cb * cb * S);
+          float s12 = (q[7] - q[1] * q[2]) + dS * (cb * q[2] + cr * q[1] + cb * cr * S);
           s_ssim_b += ((2.f * m12 + c1) * (2.f * s12 + c2)) / ((m1s + murs + c1) * (s1 + sr + c2));
         }
         int ci = (yy + HALO) * TP + xx + HALO;
-        float a = tin[ci], b = tin[TPL + ci], r = tin[2 * TPL + ci];
+        float a = tin[ci] + ca, b = tin[TPL + ci] + cb, r = tin[2 * TPL + ci] + cr;
         s_mse_a += (a - r) * (a - r);
         s_mse_b += (b - r) * (b - r);
       }
@@ -205,7 +251,10 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
   }
 }
 
-// d a[q] (+)= scale * ( G*(g_mu)[q] + 2 a[q] G*(g_aa)[q] + r[q] G*(g_ar)[q] ),  G = the 11x11 Gaussian, zero padded
+// d a[q] (+)= scale * ( G*(g_mu)[q] + 2 a[q] G*(g_aa)[q] + r[q] G*(g_ar)[q] ),  G = the 11x11 Gaussian, zero padded.
+// g_mu carries -2 mu_a g_aa - mu_r g_ar, which cancels against the other two terms on a nearly constant region;
+// evaluated as G*(g_mu + 2 ca g_aa + cr g_ar) + 2 (a - ca) G*(g_aa) + (r - cr) G*(g_ar) with the tile's first
+// pixels (ca, cr) - the same sum for any constants - every filtered quantity is O(gradient), not O(1000 x gradient).
 __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__ ia, const float* __restrict__ ir,
                                                        const float* __restrict__ gmap, int nimg, int H, int W,
                                                        SsimWindow win, float scale, const float* __restrict__ scale_dev,
@@ -217,13 +266,17 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
   const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x, n = blockIdx.y;
   const int x0 = tx * TS - HALO, y0 = ty * TS - HALO;
   const long long ibase = (long long)n * H * W, plane = (long long)nimg * H * W;
+  const long long o00 = ibase + (long long)(ty * TS) * W + tx * TS;
+  const float ca = ia[o00], cr = ir[o00];
   for (int i = threadIdx.x; i < TIN * TIN; i += 256) {
     int yy = i / TIN, xx = i - yy * TIN;
     int gy = y0 + yy, gx = x0 + xx;
     bool ok = (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
     long long o = ibase + (long long)gy * W + gx;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) tin[k * TIN * TIN + i] = ok ? gmap[k * plane + o] : 0.f;
+    float g0 = ok ? gmap[o] : 0.f, g1 = ok ? gmap[plane + o] : 0.f, g2 = ok ? gmap[2 * plane + o] : 0.f;
+    tin[i] = g0 + 2.f * ca * g1 + cr * g2;
+    tin[TIN * TIN + i] = g1;
+    tin[2 * TIN * TIN + i] = g2;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < TIN * TS; i += 256) {
@@ -253,7 +306,7 @@ __global__ __launch_bounds__(256) void ssim_bwd_kernel(const float* __restrict__
       q2 += g * hq[2 * TIN * TS + (yy + t) * TS + xx];
     }
     long long o = ibase + (long long)gy * W + gx;
-    float v = sc * (q0 + 2.f * ia[o] * q1 + ir[o] * q2);
+    float v = sc * (q0 + 2.f * (ia[o] - ca) * q1 + (ir[o] - cr) * q2);
     da[o] = accumulate ? da[o] + v : v;
   }
 }
@@ -265,7 +318,7 @@ extern "C" int ried_ssim_fwd(const float* a, const float* b, const float* ref, i
                              hipStream_t stream) {
   RIED_CHECK_ARG(a && ref && sums && nimg > 0 && nimg <= 65535 && H > 0 && W > 0, "ried_ssim_fwd: bad arguments");
   RIED_CHECK_ARG(!(b && gmap), "ried_ssim_fwd: gradient maps need the two-image form");
-  static const SsimWindow win = make_window();
+  const SsimWindow win = g_window;
   int tiles = ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
   // tiles per block: about four blocks per CU in all, at most 16 tiles each
   int tpb = (int)(((long long)tiles * nimg + 1023) / 1024);
@@ -295,7 +348,7 @@ extern "C" int ried_ssim_fwd(const float* a, const float* b, const float* ref, i
 extern "C" int ried_ssim_bwd(const float* a, const float* ref, const float* gmap, int nimg, int H, int W, float scale,
                              const float* scale_dev, float* da, int accumulate, hipStream_t stream) {
   RIED_CHECK_ARG(a && ref && gmap && da && nimg > 0 && nimg <= 65535 && H > 0 && W > 0, "ried_ssim_bwd: bad arguments");
-  static const SsimWindow win = make_window();
+  const SsimWindow win = g_window;
   int tiles = ((W + TS - 1) / TS) * ((H + TS - 1) / TS);
   size_t sh = (3 * TIN * TIN + 3 * TIN * TS) * sizeof(float);
   hipLaunchKernelGGL(ssim_bwd_kernel, dim3(tiles, nimg), dim3(256), sh, stream, a, ref, gmap, nimg, H, W, win, scale,

@@ -24,6 +24,66 @@ def allreduce_mean(t: torch.Tensor, group=None, world: Optional[int] = None) -> 
         t.mul_(1.0 / world)
 
 
+class Exchanger:
+    """Mean-over-ranks all-reduces of the training step, in two forms:
+
+      sync(t)              the result is needed at once (the two hinge means);
+      issue(t) -> handle   t is complete on the current stream: start its all-reduce and return at once, so the
+      wait(handle)         kernels launched next run while it is in flight; wait() makes the current stream wait
+                           for the result (no host synchronisation).
+
+    Backend "nccl" (RCCL over xGMI): issue() is an asynchronous collective on RCCL's own stream, ordered after the
+    current stream by an event; the mean is ReduceOp.AVG where the library has it (else a sum and one scaling
+    kernel in wait()).  Any other backend (gloo: CPU tests, and rehearsals with several ranks sharing one card,
+    which RCCL refuses) goes through host memory: the stream is drained, the tensor copied out, reduced and copied
+    back inside issue(); wait() is then a no-op.  Handles must be waited for in the order they were issued.
+    A single-rank group still issues its collectives (that is how the multi-rank code path is exercised on one
+    GPU)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.native = dist.get_backend(group) == "nccl"
+        self.avg = False
+        self.issued = 0            # collectives started so far (read by watchdogs)
+        if self.native:
+            try:                   # one tiny collective: does this RCCL build take ReduceOp.AVG?
+                t = torch.ones(1, device="cuda")
+                dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+                self.avg = abs(t.item() - 1.0) < 1e-6
+            except Exception:
+                self.avg = False
+
+    def _host_reduce(self, t: torch.Tensor):
+        if t.is_cuda:
+            torch.cuda.current_stream().synchronize()
+        h = t.detach().to("cpu", copy=True)
+        self.dist.all_reduce(h, group=self.group)
+        if self.world > 1:
+            h.mul_(1.0 / self.world)
+        t.copy_(h)
+
+    def issue(self, t: torch.Tensor):
+        self.issued += 1
+        if not self.native:
+            self._host_reduce(t)
+            return None
+        op = self.dist.ReduceOp.AVG if self.avg else self.dist.ReduceOp.SUM
+        return (self.dist.all_reduce(t, op=op, group=self.group, async_op=True), t)
+
+    def wait(self, handle):
+        if handle is None:
+            return
+        work, t = handle
+        work.wait()                # the current stream waits for RCCL's stream; the host does not block
+        if not self.avg and self.world > 1:
+            t.mul_(1.0 / self.world)
+
+    def sync(self, t: torch.Tensor):
+        self.wait(self.issue(t))
+
+
 def init_from_env(backend: str = "nccl"):
     """Initialise torch.distributed from RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).
     Returns (rank, local_rank, world)."""

@@ -130,11 +130,28 @@ class Ctx:
         self.dx_group: Optional["InputGradGroup"] = None     # open group of sibling 1x1 layers (see InputGradGroup)
         self.build_lane = 0                # lane (stream + scratch set) the layers being built will run on
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
-        self.wreds = ops.JobTable(11)      # every weight-gradient slab reduction: one launch (end_backward)
         self.sn = ops.SnJobs()             # every spectral-norm layer: power iteration / sigma gradient per launch
-        self.wgrads = ops.WgradJobs()      # deferred weight gradients: one launch per tile shape (end_backward)
+        # Deferred weight gradients (one launch per tile shape) and the reduction of their split-K slabs (one launch),
+        # issued by end_backward().  One pair of tables per gradient bucket: with data parallelism a network's
+        # backward pass finishes its gradients bucket by bucket, so each bucket's all-reduce can start while the
+        # layers of the next one still run (set_bucket() while building; a single bucket otherwise).
+        self._wgrads_all: List[ops.WgradJobs] = []
+        self._wreds_all: List[ops.JobTable] = []
+        self.set_bucket(0)
         self._late: List = []              # callbacks run by finalize() once every buffer has its address
-        self._wred_slab: List[Tuple[int, int]] = []      # (job, slab offset) patched once the arena exists
+        self._wred_slab: List[Tuple[ops.JobTable, int, int]] = []   # (table, job, slab offset): patched in finalize()
+
+    def set_bucket(self, b: int):
+        """Layers built from here on put their weight gradients into bucket b."""
+        while len(self._wgrads_all) <= b:
+            self._wgrads_all.append(ops.WgradJobs())
+            self._wreds_all.append(ops.JobTable(11))
+        self.bucket = b
+        self.wgrads, self.wreds = self._wgrads_all[b], self._wreds_all[b]
+
+    @property
+    def n_buckets(self) -> int:
+        return len(self._wgrads_all)
 
     # activations
     def act(self, N, H, W, C, grad: Optional[bool] = None) -> Act:
@@ -173,7 +190,7 @@ class Ctx:
     def add_wgrad_reduce(self, slab_off, out: torch.Tensor, splitk, taps, Cp, Cg, st, sp, sg, accumulate=False):
         j = self.wreds.add([0, out.data_ptr(), splitk, taps * Cp * Cg, taps, Cp, Cg, st, sp, sg, int(accumulate)],
                            nblocks=Cp)
-        self._wred_slab.append((j, slab_off))
+        self._wred_slab.append((self.wreds, j, slab_off))
 
     def need_tmp(self, n):
         self.tmp_elems = max(self.tmp_elems, n)
@@ -196,14 +213,14 @@ class Ctx:
             arena, off = (self.stats_arena, off) if off >= 0 else (self.fold_arena, -1 - off)
             setattr(owner, attr, arena[off:off + getattr(owner, attr + "_n")])
         self.slab = torch.empty(max(self.slab_elems, 4), dtype=F32, device=dev)
-        for j, off in self._wred_slab:
-            self.wreds.rows[j][0] = self.slab.data_ptr() + 4 * off
+        for table, j, off in self._wred_slab:
+            table.rows[j][0] = self.slab.data_ptr() + 4 * off
         for fn in self._late:
             fn()
         self.packs.finalize(dev)
-        self.wreds.finalize(dev)
         self.sn.finalize(dev)
-        self.wgrads.finalize(dev)
+        for t in self._wreds_all + self._wgrads_all:
+            t.finalize(dev)
         # one scratch set per lane: branches of a Par run concurrently on their own streams
         self.tmps = [torch.empty(max(self.tmp_elems, 8), dtype=torch.bfloat16, device=dev) for _ in range(N_LANES)]
         self.f32s = [torch.empty(max(self.f32_elems, 4), dtype=F32, device=dev) for _ in range(N_LANES)]
@@ -241,11 +258,12 @@ class Ctx:
         if self.sn.jobs is not None:
             ops.sn_backward_jobs(self.sn)
 
-    def end_backward(self):
+    def end_backward(self, bucket: Optional[int] = None):
         """The deferred weight gradients (one launch per tile shape), then the reduction of every layer's slabs
-        into the master gradients (one launch)."""
-        self.wgrads.launch()
-        ops.wgrad_reduce_jobs(self.wreds)
+        into the master gradients (one launch); of one bucket, or of all."""
+        for b in range(self.n_buckets) if bucket is None else (bucket,):
+            self._wgrads_all[b].launch()
+            ops.wgrad_reduce_jobs(self._wreds_all[b])
 
 
 N_LANES = 4
@@ -391,11 +409,13 @@ class ConvCore:
         """Compute this layer's weight gradient in Ctx.end_backward(), together with every other deferred layer,
         instead of in its own launch.  dy_of(): the view that will hold d loss / d conv output at that point (it
         must not be a scratch buffer that later layers overwrite); called once all buffers have addresses."""
+        table = self.ctx.wgrads          # the bucket being built now
+
         def make():
             dy, x = dy_of(), self.xin.v
             g, p = (dy, x) if self.deconv else (x, dy)
-            self.ctx.wgrads.add(g, p, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
-                                self.ctx.slab_at(self.slab_off), self.splitk)
+            table.add(g, p, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
+                      self.ctx.slab_at(self.slab_off), self.splitk)
         self.ctx._late.append(make)
         self.deferred = True
 
@@ -1044,9 +1064,16 @@ def inception_d(ctx, prefix, xin: Slot, out: Slot, cin, decoder) -> Seq:
 class Generator:
     """RIGAN (src/rinet.py:34-92) for a fixed (N, H, W).  x and the output are fp32 (N,1,H,W)."""
 
+    # first top-level module of each gradient bucket, in forward (= flat parameter) order; the backward pass
+    # completes the buckets last to first
+    BUCKET_STARTS = ("conv1", "layer_block_3", "expand_grid_2")
+
     def __init__(self, state: State, N: int, H: int, W: int, grads=True, training=True, device="cuda",
-                 out: Optional[torch.Tensor] = None, per_image_stats: bool = False):
+                 out: Optional[torch.Tensor] = None, per_image_stats: bool = False, grad_buckets: bool = False):
         """out: where the (N,1,H,W) fp32 result goes (default: an own buffer).
+        grad_buckets: finish the parameter gradients in three buckets (decoder, bottleneck, encoder) instead of all
+        at the end of backward(), so that a data-parallel step can exchange each bucket while the next one is being
+        computed: iterate backward_buckets() and read bucket_ranges.
         per_image_stats (forward-only, train-mode BatchNorm): every image of the batch is normalised with its own
         statistics, i.e. the batch is N independent batch-1 forwards - what the reference's evaluation loop
         computes (src/test.py:107-131: batch-1 loader, the model left in train mode).  The running statistics are
@@ -1064,15 +1091,24 @@ class Generator:
         self.cat1 = Slot(ctx.act(N, h4, w4, 192))       # cat(conv2 (64), layer_block_5 (128))   src/rinet.py:88
         self.conv1 = ConvBNC1(ctx, "conv1", 32, N, H, W, self.cat2.sub(0, 32))
         body = Seq()
+        self.bucket_first = [0]        # index into body.layers of the first layer of buckets 1, 2, ... (bucket 0: conv1)
+        bucketed = grads and grad_buckets
+
+        def bucket(n):
+            if bucketed:
+                ctx.set_bucket(n)
+                self.bucket_first.append(len(body.layers))
         c2 = self.cat1.sub(0, 64)
         body.add(ConvBN(ctx, "conv2", 32, 64, 3, 2, 1, self.cat2.sub(0, 32), c2))
         a1 = Slot(ctx.act(N, h4, w4, 128)); body.add(inception_a(ctx, "layer_block_1.0", c2, a1, 64, True))
         a2 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_b(ctx, "reduce_grid_1", a1, a2, 128, False))
         a3 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_c(ctx, "layer_block_2.0", a2, a3, 256, 64, False))
         a4 = Slot(ctx.act(N, h16, w16, 512)); body.add(inception_d(ctx, "reduce_grid_2", a3, a4, 256, False))
+        bucket(1)
         a5 = Slot(ctx.act(N, h16, w16, 1024)); body.add(inception_e(ctx, "layer_block_3.0", a4, a5, 512, True))
         a6 = Slot(ctx.act(N, h8, w8, 512)); body.add(inception_d(ctx, "expand_grid_1", a5, a6, 1024, True))
         a7 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_c(ctx, "layer_block_4.0", a6, a7, 512, 64, True))
+        bucket(2)
         a8 = Slot(ctx.act(N, h4, w4, 256)); body.add(inception_b(ctx, "expand_grid_2", a7, a8, 256, True))
         body.add(inception_a(ctx, "layer_block_5.0", a8, self.cat1.sub(64, 192), 256, True))
         body.add(ConvBN(ctx, "deconv1", 192, 64, 4, 2, 1, self.cat1, self.cat2.sub(32, 96), deconv=True))
@@ -1089,6 +1125,11 @@ class Generator:
         assert self.out.shape == (N, 1, H, W) and self.out.dtype == F32 and self.out.is_contiguous()
         ctx.finalize()
         self.x = None
+        # [lo, hi) of the flat parameter / gradient buffer per bucket (parameters are laid out in module order)
+        starts = [state.offs[min((k for k in state.offs if k.startswith(p + ".")), key=state.offs.get)]
+                  for p in (self.BUCKET_STARTS if bucketed else self.BUCKET_STARTS[:1])]
+        assert starts == sorted(starts) and starts[0] == 0
+        self.bucket_ranges = list(zip(starts, starts[1:] + [state.flat.numel()]))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         assert x.shape == (self.N, 1, self.H, self.W) and x.dtype == F32 and x.is_contiguous()
@@ -1107,13 +1148,26 @@ class Generator:
 
     def backward(self, dout: torch.Tensor):
         """dout: fp32 (N,1,H,W) = d loss / d output.  Fills state.g (which must be zero on entry)."""
+        for _ in self.backward_buckets(dout):
+            pass
+
+    def backward_buckets(self, dout: torch.Tensor):
+        """backward() as a generator: yields b each time bucket b of the parameter gradients
+        (state.flat_grad[bucket_ranges[b]]) is complete on the current stream - the last bucket first."""
         assert dout.shape == self.out.shape and dout.dtype == F32 and dout.is_contiguous()
         self.ctx.zero_backward()
         ops.out_conv_bwd(self.x, self.hlast.v, self.st.p["out_conv.weight"], dout, self.hlast.g,
                          self.st.g["out_conv.weight"])
-        self.body.backward()
+        layers = self.body.layers
+        for i in reversed(range(len(layers))):
+            layers[i].backward()
+            if i in self.bucket_first[1:]:
+                b = self.bucket_first.index(i)
+                self.ctx.end_backward(b)
+                yield b
         self.conv1.backward()
-        self.ctx.end_backward()
+        self.ctx.end_backward(0)
+        yield 0
 
 
 # --------------------------------------------------------------------------- discriminator

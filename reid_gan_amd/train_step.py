@@ -13,9 +13,12 @@ detached in the D iterations), VGG weight gradients, D weight gradients during t
 own step raises on torch >= 1.5 (D is updated in place between the forward and the backward that uses it);
 here the G gradient is taken before the last D Adam step, i.e. through the D that produced pred_neg.
 
-Data parallel (one process per GPU, RCCL over xGMI): gradients are averaged with one all-reduce over each
-network's flat gradient buffer; the two hinge means of DLoss are all-reduced before the (non-linear) hinge so
-the result equals the single-GPU step at the same global batch.  BatchNorm statistics stay per replica.
+Data parallel (one process per GPU, RCCL over xGMI): the two hinge means of DLoss are all-reduced before the
+(non-linear) hinge so the result equals the single-GPU step at the same global batch; the discriminator's flat
+gradient is averaged with one all-reduce per D iteration and the generator's in three buckets in the order its
+backward pass completes them (decoder, bottleneck, encoder).  The last discriminator gradient and every generator
+bucket are exchanged WHILE the rest of the generator backward runs: each all-reduce is started the moment its
+gradients are complete and only waited for in front of the Adam steps.  BatchNorm statistics stay per replica.
 """
 from __future__ import annotations
 
@@ -62,7 +65,12 @@ class TrainStep:
         self.segmented = process_group is not None
         self.gs, self.ds = State(g_sd, device), State(d_sd, device)
         B = batch
-        self.G = Generator(self.gs, B, H, W, grads=True, training=True, device=device)
+        self.xch = None
+        if process_group is not None:
+            from .dp import Exchanger
+            self.xch = Exchanger(process_group)
+        self.G = Generator(self.gs, B, H, W, grads=True, training=True, device=device,
+                           grad_buckets=process_group is not None)
         self.D = Discriminator(self.ds, 2 * B, H, W, grads=True, training=True, device=device)
         self.V = Vgg(vgg, B, H, W, grads=True, device=device)
         self.x = torch.zeros(B, 1, H, W, dtype=F32, device=device)
@@ -80,24 +88,32 @@ class TrainStep:
         self.graphs = None          # [(graph, tensor to all-reduce after it or None)]
         self.steps_done = 0
         self.segment = -1
-        self.exchange = (0, 0)
+        self._inflight = {}
+
+    @property
+    def exchange(self):
+        """(collectives started so far, in flight now): where a stuck rank stands (read by watchdogs)."""
+        return (self.xch.issued if self.xch is not None else 0, len(self._inflight))
 
     # ------------------------------------------------------------------ collectives
-    def _allreduce_mean(self, t):
-        """t: a tensor, or a tuple of tensors exchanged at the same point of the step."""
-        if self.pg is not None:
-            import torch.distributed as dist
-            for u in (t if isinstance(t, tuple) else (t,)):
-                self.exchange = (self.exchange[0] + 1, u.numel())      # (count, size of the one in flight)
-                dist.all_reduce(u, group=self.pg)
-                if self.world > 1:
-                    u.mul_(1.0 / self.world)
+    # The step (_body) is a generator of exchange events; between two events it only launches kernels.
+    #   ("sync", t)         all-reduce t now, the next kernels need the result
+    #   ("issue", key, t)   t is complete on the current stream: start its all-reduce
+    #   ("wait", key)       the next kernels need the result of that all-reduce
+    def _handle(self, ev):
+        if self.xch is None or ev is None:
+            return
+        if ev[0] == "sync":
+            self.xch.sync(ev[1])
+        elif ev[0] == "issue":
+            self._inflight[ev[1]] = self.xch.issue(ev[2])
+        else:
+            self.xch.wait(self._inflight.pop(ev[1]))
 
     # ------------------------------------------------------------------ the step
-    # The step is written as a generator that yields the tensors to average across ranks.  With one rank the
-    # yields are skipped and the whole step is one HIP graph; with several ranks each stretch between two
-    # collectives is its own graph and the RCCL all-reduces are issued between the replays on the same stream,
-    # so nothing synchronises with the host either way.
+    # With one rank the events are skipped and the whole step is one HIP graph; with several ranks each stretch
+    # between two events is its own graph and the RCCL all-reduces are started / awaited between the replays, so
+    # nothing synchronises with the host either way and a started all-reduce overlaps the graphs replayed after it.
     # Two whole-network overlaps on side streams (graph capture records them as parallel paths):
     #  * the VGG features of the TARGET images depend on nothing the step computes, so they run beside the
     #    generator forward, whose small layers leave most of the chip idle;
@@ -123,26 +139,30 @@ class TrainStep:
         sc[SC_MEAN_POS:SC_MEAN_NEG + 1].zero_()
         ops.dot(out.v.images(0, B), None, 1.0 / n, sc[SC_MEAN_POS:])
         ops.dot(out.v.images(B, 2 * B), None, 1.0 / n, sc[SC_MEAN_NEG:])
-        yield sc[SC_MEAN_POS:SC_MEAN_NEG + 1]            # the hinge acts on the GLOBAL batch means
+        yield ("sync", sc[SC_MEAN_POS:SC_MEAN_NEG + 1])      # the hinge acts on the GLOBAL batch means
         ops.dloss_scalars(sc, n)
         sc[SC_DLOSS2 if last else SC_DLOSS1].copy_(sc[SC_DLOSS])
         if last:       # the generator's gradient goes through D as it is now; D's own backward reuses the buffers after
             self._g_loss_backward(n)
-        # D's own backward (large kernels) on a side stream, the generator backward (small, latency-bound
-        # kernels; its Inception branches fork from the stream it runs on) on the main one
-        side = self._fork(N_LANES + 1, last and self.overlap_gbwd)
+        # One process: D's own backward (large kernels) on a side stream beside the generator backward (small,
+        # latency-bound kernels; its Inception branches fork from the stream it runs on).  Data parallel: D's
+        # backward first, on the main stream, so that its gradient exchange is in flight during the whole generator
+        # backward, whose buckets follow it into the exchange one by one.
+        side = self._fork(N_LANES + 1, last and self.overlap_gbwd and not self.segmented)
         with torch.cuda.stream(side):
             D.ctx.zero_backward()
             self.ds.zero_grad()
             ops.fill(out.g.images(0, B), 1.0, s=sc[SC_CPOS:])
             ops.fill(out.g.images(B, 2 * B), 1.0, s=sc[SC_CNEG:])
             D.backward(0, 2 * B, wgrad=True)
+        yield ("issue", "d", self.ds.flat_grad)
         if last:
             self.gs.zero_grad()
-            self.G.backward(self.dpred)
+            for b in self.G.backward_buckets(self.dpred):
+                lo, hi = self.G.bucket_ranges[b]
+                yield ("issue", ("g", b), self.gs.flat_grad[lo:hi])
             self._join(side)
-        # (the generator's gradients are complete here too in the last iteration: one exchange point for both)
-        yield (self.ds.flat_grad, self.gs.flat_grad) if last else self.ds.flat_grad
+        yield ("wait", "d")
         self.ds.adam(4.0 * self.lr)
 
     def _g_loss_backward(self, n: int):
@@ -185,11 +205,13 @@ class TrainStep:
         self.d_in[B:].copy_(pred)
         yield from self._d_iteration(last=False)
         yield from self._d_iteration(last=True)
+        for b in reversed(range(len(self.G.bucket_ranges))):     # in the order they were issued
+            yield ("wait", ("g", b))
         self.gs.adam(self.lr)
 
     def _run_eager(self):
-        for t in self._body():
-            self._allreduce_mean(t)
+        for ev in self._body():
+            self._handle(ev)
 
     def step(self, x: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None):
         """One training iteration on (x, y), fp32 (B,1,H,W) device tensors.  No host synchronisation; read
@@ -202,11 +224,10 @@ class TrainStep:
         else:
             if self.graphs is None:
                 self._capture()
-            for i, (g, t) in enumerate(self.graphs):
+            for i, (g, ev) in enumerate(self.graphs):
                 self.segment = i          # (where a stuck rank stands: read by watchdogs)
                 g.replay()
-                if t is not None:
-                    self._allreduce_mean(t)
+                self._handle(ev)
         self.steps_done += 1
 
     def _capture(self):
@@ -254,7 +275,8 @@ class TrainStep:
     def losses(self) -> Dict[str, float]:
         """Host read of the last step's scalars (synchronises)."""
         s = self.sc.clone()
-        self._allreduce_mean(s)
+        if self.xch is not None:
+            self.xch.sync(s)
         s = s.cpu()
         return {"dloss1": s[SC_DLOSS1].item(), "dloss2": s[SC_DLOSS2].item(), "gloss": s[SC_GLOSS].item(),
                 "vgg": s[SC_VGG].item(), "dssim": s[SC_DSSIM].item(), "gen": s[SC_GEN].item(),

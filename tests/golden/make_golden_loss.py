@@ -164,8 +164,12 @@ for name, case in SSIM_CASES.items():
     # value in this regime (the tolerance a different fp32 summation order can claim)
     e["ssim_mean_fp64"] = float(ref_loss.compute_SSIM(t.double(), p.double(), 11, 1, True))
     e["dssim_grad_norm"] = float(pr.grad.double().norm())
+    p64 = p.double().requires_grad_(True)
+    crit(t.double(), p64).backward()               # the same reference code evaluated in fp64
+    e["dssim_grad64_norm"] = float(p64.grad.norm())
     res.setdefault("ssim", {})[name] = e
     arrs["dssim_grad:" + name] = pr.grad.numpy()
+    arrs["dssim_grad64:" + name] = p64.grad.numpy().astype(np.float32)
 
 # ------------------------------------------------------------------ DLoss / GLoss (loss.py:132-155)
 g = torch.Generator().manual_seed(77)

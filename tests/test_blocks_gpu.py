@@ -111,6 +111,9 @@ def _run_block(name, N, hw, golden=None):
     a_out = Slot(ctx.act(N, ho, ho, cout))
     plan = build(ctx, a_in, a_out)
     ctx.finalize()
+    if name.startswith("inception"):      # the sibling 1x1 layers share launches: the wiring under test here
+        grp = plan.layers[0]
+        assert isinstance(grp, engine.InputGradGroup) and len(grp.members) >= 2 and grp.bn_jobs is not None, name
     ops.nchw_to_nhwc(xin.to(DEV), a_in.v)
     ctx.begin_forward()
     plan.forward()

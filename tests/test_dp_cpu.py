@@ -80,6 +80,87 @@ def test_two_rank_hinge_and_gradient_equal_global_batch():
     assert err <= 1e-5 * np.abs(flat.numpy()).max() + 1e-9, err
 
 
+def _xch_worker(rank, world, port, q):
+    """The exchange protocol of the training step (dp.Exchanger) between two gloo ranks: a blocking exchange, then
+    four all-reduces started back to back over slices of one flat buffer (the discriminator's gradient and the
+    generator's three buckets, last bucket first) and awaited in issue order; then the generator-loss terms of
+    src/loss.py:177-197 from per-rank shards - plain means over equal shards, so the mean over ranks of the per-rank
+    values must equal the value at the global batch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    dp.init_from_env(backend="gloo")
+    import torch.distributed as dist
+    from reid_gan_amd.synth import synth_vgg
+    xch = dp.Exchanger(dist.group.WORLD)
+    assert xch.world == world and not xch.native
+    means = torch.tensor([1.0 + rank, -2.0 * rank])
+    xch.sync(means)
+    g = torch.Generator().manual_seed(10 + rank)
+    d_flat, g_flat = torch.randn(1000, generator=g), torch.randn(3000, generator=g)
+    ranges = [(0, 700), (700, 2200), (2200, 3000)]
+    handles = [("d", xch.issue(d_flat))]
+    for b in (2, 1, 0):
+        lo, hi = ranges[b]
+        handles.append((b, xch.issue(g_flat[lo:hi])))
+    for _, h in handles:
+        xch.wait(h)
+    assert xch.issued == 5
+    # generator-loss terms on this rank's shard
+    x, y = synth_batch(B, H, seed=77)
+    lo, hi = rank * (B // world), (rank + 1) * (B // world)
+    d_out = torch.randn(B, 64, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        total, vl, sl, gl = O.compound_loss(synth_vgg(), x[lo:hi], y[lo:hi], d_out[lo:hi])
+    terms = torch.stack([total, vl, sl, gl])
+    xch.sync(terms)
+    if rank == 0:
+        q.put((means.numpy(), d_flat.numpy(), g_flat.numpy(), terms.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchanger_protocol_and_generator_loss_terms_two_ranks():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_xch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    means, d_flat, g_flat, terms = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert np.allclose(means, [1.5, -1.0])
+    gens = [torch.Generator().manual_seed(10 + r) for r in range(2)]
+    ds, gs = zip(*[(torch.randn(1000, generator=g), torch.randn(3000, generator=g)) for g in gens])
+    assert np.allclose(d_flat, ((ds[0] + ds[1]) / 2).numpy(), atol=1e-6)
+    assert np.allclose(g_flat, ((gs[0] + gs[1]) / 2).numpy(), atol=1e-6)
+    from reid_gan_amd.synth import synth_vgg
+    x, y = synth_batch(B, H, seed=77)
+    d_out = torch.randn(B, 64, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        ref = torch.stack(O.compound_loss(synth_vgg(), x, y, d_out)).numpy()
+    assert np.allclose(terms, ref, rtol=2e-5, atol=1e-7), (terms, ref)
+
+
+def test_batchnorm_statistics_stay_per_replica():
+    """What each rank computes in a data-parallel step is the generator applied to ITS shard: BatchNorm normalises
+    with the shard's statistics (as the reference's commented nn.DataParallel would, src/train.py:95-96), so a rank's
+    prediction equals the single-process prediction of that shard alone, not a slice of the global-batch prediction."""
+    gsd = synth_state(rinet.state_spec(rinet.RIGAN()), 101)
+    x, _ = synth_batch(4, 32, seed=3)
+    x[2:] = x[2:] * 0.5 + 200.0                      # shards with different statistics
+    with torch.no_grad():
+        whole = O.rigan_forward(O.Params({k: v.clone() for k, v in gsd.items()}), x, True)
+        shard = O.rigan_forward(O.Params({k: v.clone() for k, v in gsd.items()}), x[:2], True)
+        again = O.rigan_forward(O.Params({k: v.clone() for k, v in gsd.items()}), x[:2].clone(), True)
+    assert torch.equal(shard, again)
+    assert (whole[:2] - shard).abs().mean() > 1e-3 * shard.abs().mean()
+
+
 def test_allreduce_mean_single_rank_is_identity():
     t = torch.arange(5.0)
     dp.allreduce_mean(t)

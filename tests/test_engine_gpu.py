@@ -345,15 +345,21 @@ def test_train_step_at_128_patches():
 
 def test_train_step_at_the_benchmark_batch():
     """Batch 128 of 64 x 64 (BASELINE configs[1], what bench.py times): the plan picks other convolution tiles,
-    BatchNorm statistics folding, split-K factors and grouped weight-gradient shapes than at batch 4.  Against the
-    oracle with bf16 storage emulated.  With 128 patches every BatchNorm layer averages over >= 2048 samples, so the
-    generator is far less chaotic than at batch 2-4 and EVERY gradient tensor is held to cosine >= 0.95."""
+    BatchNorm statistics folding, split-K factors and grouped weight-gradient shapes than at batch 4.
+
+    Losses, prediction, d gloss / d pred and the discriminator's gradients: against the oracle with bf16 storage
+    emulated, at the tolerances of the small-batch test.  Generator gradients: bf16 storage makes them noisy on these
+    seeded weights whatever computes them - the oracle's own emulation and its fp32 run agree only to cosine 0.63-1.0
+    per tensor (mean 0.88) at this batch - so every tensor is held to a bound calibrated by that pair: the engine must
+    be at least as close to the emulation as the fp32 run is (minus 0.1), or above 0.95, with its norm within 30 % (or
+    twice the fp32 run's own deviation); a mis-wired layer (cosine ~ 0, or a norm off by a factor) fails either way.
+    Measured: mean cosine 0.934 against 0.880 for the fp32 run, closer than it on 221 of 222 tensors."""
     B, H = 128, 64
     gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
     x, y = synth_batch(B, H, seed=1234)
-    ost = O.TrainState(gsd, dsd, vgg, lr=1e-4)
     with emu():
-        ref = O.train_step(ost, x, y, want_grads=True)
+        ref = O.train_step(O.TrainState(gsd, dsd, vgg, lr=1e-4), x, y, want_grads=True)
+    f32 = O.train_step(O.TrainState(gsd, dsd, vgg, lr=1e-4), x, y, want_grads=True)
     ts = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
     ts.step(x.to(DEV), y.to(DEV))
     got = ts.losses()
@@ -364,13 +370,26 @@ def test_train_step_at_the_benchmark_batch():
     for k, g in ref["d_grads_1"].items():
         if not k.endswith("key_conv.bias"):
             grad_close(ts.ds.g[k].cpu(), g, "D " + k, cos=0.98, ratio=0.08)
-    bad = []
+
+    def cos_ratio(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return (torch.dot(a, b) / (a.norm() * b.norm() + 1e-300)).item(), (a.norm() / (b.norm() + 1e-300)).item()
+    bad, closer, rows = [], 0, []
     for k, g in ref["g_grads"].items():
-        try:
-            grad_close(ts.gs.g[k].cpu(), g, "G " + k, cos=0.95, ratio=0.15)
-        except AssertionError as e:
-            bad.append(str(e))
+        c_eng, r_eng = cos_ratio(ts.gs.g[k].cpu(), g)
+        c_ref, r_ref = cos_ratio(f32["g_grads"][k], g)
+        rows.append((c_eng, c_ref, r_eng, r_ref, k))
+        closer += c_eng >= c_ref
+        if c_eng < min(0.95, c_ref - 0.1) or abs(r_eng - 1) > max(0.3, 2.0 * abs(r_ref - 1)):
+            bad.append((k, round(c_eng, 4), round(c_ref, 4), round(r_eng, 3), round(r_ref, 3)))
+    rows.sort()
+    print("worst generator gradients (cos engine-emu, cos fp32-emu, norm ratios):", rows[:8])
+    print("mean cosine engine-emu %.4f, fp32-emu %.4f; engine closer on %d of %d tensors"
+          % (sum(r[0] for r in rows) / len(rows), sum(r[1] for r in rows) / len(rows), closer, len(rows)))
     assert not bad, (len(bad), bad[:12])
+    assert sum(r[0] for r in rows) >= sum(r[1] for r in rows), "on average further from the emulation than fp32 is"
+    for k in ("out_conv.weight", "deconv2.deconv.weight", "deconv1.deconv.weight"):
+        grad_close(ts.gs.g[k].cpu(), ref["g_grads"][k], "G " + k, cos=0.95, ratio=0.08)
 
 
 def test_inference_at_the_benchmark_size_vs_oracle():
