@@ -1066,14 +1066,15 @@ class Generator:
 
     # first top-level module of each gradient bucket, in forward (= flat parameter) order; the backward pass
     # completes the buckets last to first
-    BUCKET_STARTS = ("conv1", "layer_block_3", "expand_grid_2")
+    BUCKET_STARTS = ("conv1", "layer_block_3")
 
     def __init__(self, state: State, N: int, H: int, W: int, grads=True, training=True, device="cuda",
                  out: Optional[torch.Tensor] = None, per_image_stats: bool = False, grad_buckets: bool = False):
         """out: where the (N,1,H,W) fp32 result goes (default: an own buffer).
-        grad_buckets: finish the parameter gradients in three buckets (decoder, bottleneck, encoder) instead of all
-        at the end of backward(), so that a data-parallel step can exchange each bucket while the next one is being
-        computed: iterate backward_buckets() and read bucket_ranges.
+        grad_buckets: finish the parameter gradients in two buckets - bottleneck + decoder (81 % of the parameters,
+        complete after the first half of the backward pass), then the encoder - instead of all at the end of
+        backward(), so that a data-parallel step can exchange the first while the second is being computed: iterate
+        backward_buckets() and read bucket_ranges.
         per_image_stats (forward-only, train-mode BatchNorm): every image of the batch is normalised with its own
         statistics, i.e. the batch is N independent batch-1 forwards - what the reference's evaluation loop
         computes (src/test.py:107-131: batch-1 loader, the model left in train mode).  The running statistics are
@@ -1108,7 +1109,6 @@ class Generator:
         a5 = Slot(ctx.act(N, h16, w16, 1024)); body.add(inception_e(ctx, "layer_block_3.0", a4, a5, 512, True))
         a6 = Slot(ctx.act(N, h8, w8, 512)); body.add(inception_d(ctx, "expand_grid_1", a5, a6, 1024, True))
         a7 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_c(ctx, "layer_block_4.0", a6, a7, 512, 64, True))
-        bucket(2)
         a8 = Slot(ctx.act(N, h4, w4, 256)); body.add(inception_b(ctx, "expand_grid_2", a7, a8, 256, True))
         body.add(inception_a(ctx, "layer_block_5.0", a8, self.cat1.sub(64, 192), 256, True))
         body.add(ConvBN(ctx, "deconv1", 192, 64, 4, 2, 1, self.cat1, self.cat2.sub(32, 96), deconv=True))

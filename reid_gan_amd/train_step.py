@@ -15,10 +15,11 @@ here the G gradient is taken before the last D Adam step, i.e. through the D tha
 
 Data parallel (one process per GPU, RCCL over xGMI): the two hinge means of DLoss are all-reduced before the
 (non-linear) hinge so the result equals the single-GPU step at the same global batch; the discriminator's flat
-gradient is averaged with one all-reduce per D iteration and the generator's in three buckets in the order its
-backward pass completes them (decoder, bottleneck, encoder).  The last discriminator gradient and every generator
-bucket are exchanged WHILE the rest of the generator backward runs: each all-reduce is started the moment its
-gradients are complete and only waited for in front of the Adam steps.  BatchNorm statistics stay per replica.
+gradient is averaged with one all-reduce per D iteration and the generator's in two buckets in the order its
+backward pass completes them (bottleneck + decoder: 81 % of the parameters; then the encoder).  The last
+discriminator gradient and the generator's first bucket are exchanged WHILE the second half of the generator
+backward runs: each all-reduce is started the moment its gradients are complete and only waited for in front of the
+Adam steps.  BatchNorm statistics stay per replica.
 """
 from __future__ import annotations
 
@@ -96,19 +97,21 @@ class TrainStep:
         return (self.xch.issued if self.xch is not None else 0, len(self._inflight))
 
     # ------------------------------------------------------------------ collectives
-    # The step (_body) is a generator of exchange events; between two events it only launches kernels.
+    # The step (_body) is a generator of exchange points; between two of them it only launches kernels.  Each
+    # point is a list of events handled in order:
     #   ("sync", t)         all-reduce t now, the next kernels need the result
     #   ("issue", key, t)   t is complete on the current stream: start its all-reduce
     #   ("wait", key)       the next kernels need the result of that all-reduce
-    def _handle(self, ev):
-        if self.xch is None or ev is None:
+    def _handle(self, events):
+        if self.xch is None or events is None:
             return
-        if ev[0] == "sync":
-            self.xch.sync(ev[1])
-        elif ev[0] == "issue":
-            self._inflight[ev[1]] = self.xch.issue(ev[2])
-        else:
-            self.xch.wait(self._inflight.pop(ev[1]))
+        for ev in events:
+            if ev[0] == "sync":
+                self.xch.sync(ev[1])
+            elif ev[0] == "issue":
+                self._inflight[ev[1]] = self.xch.issue(ev[2])
+            else:
+                self.xch.wait(self._inflight.pop(ev[1]))
 
     # ------------------------------------------------------------------ the step
     # With one rank the events are skipped and the whole step is one HIP graph; with several ranks each stretch
@@ -139,30 +142,37 @@ class TrainStep:
         sc[SC_MEAN_POS:SC_MEAN_NEG + 1].zero_()
         ops.dot(out.v.images(0, B), None, 1.0 / n, sc[SC_MEAN_POS:])
         ops.dot(out.v.images(B, 2 * B), None, 1.0 / n, sc[SC_MEAN_NEG:])
-        yield ("sync", sc[SC_MEAN_POS:SC_MEAN_NEG + 1])      # the hinge acts on the GLOBAL batch means
+        yield [("sync", sc[SC_MEAN_POS:SC_MEAN_NEG + 1])]    # the hinge acts on the GLOBAL batch means
         ops.dloss_scalars(sc, n)
         sc[SC_DLOSS2 if last else SC_DLOSS1].copy_(sc[SC_DLOSS])
         if last:       # the generator's gradient goes through D as it is now; D's own backward reuses the buffers after
             self._g_loss_backward(n)
-        # One process: D's own backward (large kernels) on a side stream beside the generator backward (small,
-        # latency-bound kernels; its Inception branches fork from the stream it runs on).  Data parallel: D's
-        # backward first, on the main stream, so that its gradient exchange is in flight during the whole generator
-        # backward, whose buckets follow it into the exchange one by one.
-        side = self._fork(N_LANES + 1, last and self.overlap_gbwd and not self.segmented)
+        # D's own backward (large kernels) on a side stream beside the generator backward (small, latency-bound
+        # kernels; its Inception branches fork from the stream it runs on).  Data parallel: the side stream rejoins
+        # when the generator's first gradient bucket is complete, and both exchanges start there, in flight during
+        # the second half of the generator backward.
+        side = self._fork(N_LANES + 1, last and self.overlap_gbwd)
         with torch.cuda.stream(side):
             D.ctx.zero_backward()
             self.ds.zero_grad()
             ops.fill(out.g.images(0, B), 1.0, s=sc[SC_CPOS:])
             ops.fill(out.g.images(B, 2 * B), 1.0, s=sc[SC_CNEG:])
             D.backward(0, 2 * B, wgrad=True)
-        yield ("issue", "d", self.ds.flat_grad)
-        if last:
-            self.gs.zero_grad()
-            for b in self.G.backward_buckets(self.dpred):
-                lo, hi = self.G.bucket_ranges[b]
-                yield ("issue", ("g", b), self.gs.flat_grad[lo:hi])
-            self._join(side)
-        yield ("wait", "d")
+        if not last:
+            yield [("sync", self.ds.flat_grad)]
+            self.ds.adam(4.0 * self.lr)
+            return
+        self.gs.zero_grad()
+        gr, first = self.G.bucket_ranges, True
+        for b in self.G.backward_buckets(self.dpred):
+            ev = [("issue", ("g", b), self.gs.flat_grad[gr[b][0]:gr[b][1]])]
+            if first:
+                self._join(side)
+                ev.insert(0, ("issue", "d", self.ds.flat_grad))
+                first = False
+            if b == 0:      # the last bucket: everything is needed next
+                ev += [("wait", "d")] + [("wait", ("g", k)) for k in reversed(range(len(gr)))]
+            yield ev
         self.ds.adam(4.0 * self.lr)
 
     def _g_loss_backward(self, n: int):
@@ -205,8 +215,6 @@ class TrainStep:
         self.d_in[B:].copy_(pred)
         yield from self._d_iteration(last=False)
         yield from self._d_iteration(last=True)
-        for b in reversed(range(len(self.G.bucket_ranges))):     # in the order they were issued
-            yield ("wait", ("g", b))
         self.gs.adam(self.lr)
 
     def _run_eager(self):
