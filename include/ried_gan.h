@@ -221,6 +221,21 @@ int ried_dot(const void* a, long long lda, const void* b, long long ldb, long lo
  * [0, d), k in [d, 2d); P bf16 [nimg][n][n].  Only the (n, d) for which ried_attn_scores_softmax_supported is 1. */
 int ried_attn_scores_softmax_supported(int n, int d);
 int ried_attn_scores_softmax(const void* qkv, long long ld, int nimg, int n, int d, void* P, ried_stream_t stream);
+/* Self_Attn (src/rinet.py:162-181) fused, for the (n, d, C) ried_attn_fused_supported accepts ((256, 32, 256) and
+ * (64, 64, 512): the two layers at 64 x 64 patches): energy, softmax and the value product in one kernel, nothing
+ * n x n in HBM.  qkv: bf16 [nimg][n][ld] with q in channels [0, d), k in [d, 2d), v in [2d, 2d + C) (the output of
+ * the fused query / key / value 1x1 convolution); x: the layer input [nimg][n] (view, ldx).
+ * ried_attn_fwd: O [nimg][n] (view, ldO) = attention . v;  out = gamma[0] * O + x (src/rinet.py:180);
+ *   lse fp32 [nimg][n] = log sum_j exp(energy[i][j]) (what the backward pass rebuilds the attention from).
+ * ried_attn_bwd (autograd of the above): dout = d loss / d out; dqkv (view, ldg, all 2d + C channels written) =
+ *   gradients w.r.t. q, k, v; dgamma[0] += sum dout * O (NULL: not wanted).  The residual path dx += dout is the
+ *   caller's. */
+int ried_attn_fused_supported(int n, int d, int C);
+int ried_attn_fwd(const void* qkv, long long ld, const void* x, long long ldx, void* out, long long ldo, void* O,
+                  long long ldO, float* lse, const float* gamma, int nimg, int n, int d, int C, ried_stream_t stream);
+int ried_attn_bwd(const void* qkv, long long ld, void* dqkv, long long ldg, const void* dout, long long lddo,
+                  const void* O, long long ldO, const float* lse, const float* gamma, float* dgamma, int nimg, int n,
+                  int d, int C, ried_stream_t stream);
 /* out = s ? s[0] * value : value over a bf16 view */
 int ried_fill(void* out, long long ldo, long long npix, int C, const float* s, float value, ried_stream_t stream);
 int ried_softmax_fwd(const float* S, void* P, long long rows, int n, ried_stream_t stream); /* src/rinet.py:174 */

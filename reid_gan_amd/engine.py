@@ -700,6 +700,7 @@ class InputGradGroup:
 
 
 SIBLING_GROUPS = not os.environ.get("RIED_NO_SIBLING_GROUPS")      # switch for A/B runs and tests
+FUSED_ATTN = not os.environ.get("RIED_NO_FUSED_ATTN")
 FWD_BN_JOBS = not os.environ.get("RIED_NO_FWD_BN_JOBS")
 
 
@@ -1263,13 +1264,18 @@ class Attn:
         self.wcat = st.flat[ow:ow + self.cq * C].view(self.cq, C)           # [q; k; v] projection weights
         self.bias = st.flat[ob:ob + self.cq]
         ctx.add_pack(self.wcat, self.wp, self.cq, 1, 1, C, C, 1, 1, 1)
-        self.S = torch.empty(N * self.n * self.n, dtype=F32, device=dev)
-        self.P = torch.empty(N * self.n * self.n, dtype=torch.bfloat16, device=dev)
+        self.fused = FUSED_ATTN and ops.attn_fused_supported(self.n, self.d, C)    # one kernel each way, no n x n tensors
         self.O = ops.new_view(N, H, W, C, dev)
+        if self.fused:
+            self.lse = torch.empty(N * self.n, dtype=F32, device=dev)
+        else:
+            self.S = torch.empty(N * self.n * self.n, dtype=F32, device=dev)
+            self.P = torch.empty(N * self.n * self.n, dtype=torch.bfloat16, device=dev)
         if ctx.grads:
             self.wpt = torch.empty(self.cq * C, dtype=torch.bfloat16, device=dev)
-            self.dS = torch.empty(N * self.n * self.n, dtype=torch.bfloat16, device=dev)
-            self.dO = ops.new_view(N, H, W, C, dev)
+            if not self.fused:
+                self.dS = torch.empty(N * self.n * self.n, dtype=torch.bfloat16, device=dev)
+                self.dO = ops.new_view(N, H, W, C, dev)
             self.dw = st.flat_grad[ow:ow + self.cq * C]
             self.db = st.flat_grad[ob:ob + self.cq]
             ctx.add_pack(self.wcat, self.wpt, C, 1, 1, self.cq, 1, 1, 1, C)   # [C][1][1][cq] for the data gradient
@@ -1290,6 +1296,9 @@ class Attn:
         st, C, d, n, N = self.ctx.st, self.C, self.d, self.n, self.N
         x, qkv = self.xin.v, self.qkv.v
         ops.conv2d(x, self.wp, qkv, 1, 1, 1, 1, 0, 0, bias=self.bias)
+        if self.fused:
+            ops.attn_fwd(qkv, x, self.out.v, self.O, self.lse, st.p[self.prefix + ".gamma"], d)
+            return
         q, k, v = qkv.ptr, qkv.ptr + 2 * d, qkv.ptr + 4 * d
         ld, bs = qkv.ld, n * qkv.ld
         # S[b][i][j] = q_i . k_j : m = j (A = k), n = i (B = q)
@@ -1306,10 +1315,16 @@ class Attn:
         st, C, d, n = self.ctx.st, self.C, self.d, self.n
         N = n1 - n0
         out, xin, qkv = self.out.images(n0, n1), self.xin.images(n0, n1), self.qkv.images(n0, n1)
-        O, dO = self.O.images(n0, n1), self.dO.images(n0, n1)
+        O = self.O.images(n0, n1)
         gamma = st.p[self.prefix + ".gamma"]
         if out.g.ptr != xin.g.ptr:      # residual path (first writer of xin.g); free when the two views alias
             ops.ew(ops.EW_COPY, out.g, xin.g)
+        if self.fused:
+            ops.attn_bwd(qkv.v, qkv.g, out.g, O, self.lse.data_ptr() + 4 * n0 * n, gamma,
+                         st.g[self.prefix + ".gamma"] if wgrad else None, d)
+            self._backward_projection(xin, qkv, wgrad)
+            return
+        dO = self.dO.images(n0, n1)
         if wgrad:
             ops.dot(out.g, O, 1.0, st.g[self.prefix + ".gamma"])
         ops.ew(ops.EW_SCALE, out.g, dO, s=gamma)
@@ -1329,6 +1344,10 @@ class Attn:
         ops.bgemm(k, ld, bs, 1, dS, n, n * n, 0, d, n, n, N, dq, ld, bs)
         # dk[j][e] = sum_i dS[i][j] q[i][e] : m = e (A = q stored [i][e]), n = j (B = dS stored [i][j])
         ops.bgemm(q, ld, bs, 1, dS, n, n * n, 1, d, n, n, N, dk, ld, bs)
+        self._backward_projection(xin, qkv, wgrad)
+
+    def _backward_projection(self, xin, qkv, wgrad: bool):
+        """Backward of the fused [q; k; v] 1x1 convolution from qkv.g."""
         if wgrad:             # bias and weight gradients land directly in the state's (zeroed) gradient buffer
             ops.colsum(qkv.g, self.db, self.ctx.f32)
             ops.conv2d_wgrad(xin.v, qkv.g, 1, 1, 1, 1, 0, 0, self.ctx.slab_at(self.slab_off), self.splitk)

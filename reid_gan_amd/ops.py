@@ -151,6 +151,22 @@ def attn_scores_softmax(qkv: View, d: int, P: torch.Tensor):
     lib.ried_attn_scores_softmax(qkv.ptr, qkv.ld, qkv.N, qkv.H * qkv.W, d, _p(P), _stream())
 
 
+def attn_fused_supported(n: int, d: int, C: int) -> bool:
+    return bool(lib.ried_attn_fused_supported(n, d, C))
+
+
+def attn_fwd(qkv: View, x: View, out: View, O: View, lse: torch.Tensor, gamma: torch.Tensor, d: int):
+    """Fused Self_Attn forward on the [q; k; v] projection: O = softmax(q^T k) v, out = gamma * O + x, lse per query."""
+    lib.ried_attn_fwd(qkv.ptr, qkv.ld, x.ptr, x.ld, out.ptr, out.ld, O.ptr, O.ld, _p(lse), _p(gamma), qkv.N,
+                      qkv.H * qkv.W, d, O.C, _stream())
+
+
+def attn_bwd(qkv: View, dqkv: View, dout: View, O: View, lse_ptr: int, gamma: torch.Tensor, dgamma, d: int):
+    """Fused Self_Attn backward: dqkv = gradients of q, k, v; dgamma[0] += sum dout * O (None: skipped)."""
+    lib.ried_attn_bwd(qkv.ptr, qkv.ld, dqkv.ptr, dqkv.ld, dout.ptr, dout.ld, O.ptr, O.ld, lse_ptr, _p(gamma),
+                      _p(dgamma), qkv.N, qkv.H * qkv.W, d, O.C, _stream())
+
+
 def bgemm(A, lda, bsa, a_tr, B, ldb, bsb, b_tr, M, N, K, batch, out, ldc, bsc, out_f32=False, alpha=1.0,
           gamma=None, resid=None, ld_resid=0, bs_resid=0, accumulate=False):
     lib.ried_bgemm(A, lda, bsa, int(a_tr), B, ldb, bsb, int(b_tr), M, N, K, batch, out, ldc, bsc, int(out_f32),

@@ -972,3 +972,55 @@ def test_metrics_three_image_form():
         o, q = O.compute_measure(xi, yi, pi, 400.0)
         assert abs(s[i, 0] - o[1]) < 2e-5 and abs(s[i, 2] - q[1]) < 2e-5
         assert abs(s[i, 1].sqrt() - o[2]) < 1e-3 * o[2] and abs(s[i, 3].sqrt() - q[2]) < 1e-3 * q[2]
+
+
+@pytest.mark.parametrize("n,d,C", [(256, 32, 256), (64, 64, 512)])
+def test_fused_attention_forward_backward(n, d, C):
+    """ried_attn_fwd / ried_attn_bwd (Self_Attn, src/rinet.py:162-181, without its three projections) against torch
+    autograd in fp32 on the bf16-rounded inputs.  Tolerances relative to each tensor's largest value: outputs 1.5e-2
+    (bf16 storage of the attention weights and of O), gradients 3e-2, lse 1e-3 absolute."""
+    N, side = 3, int(n ** 0.5)
+    qkv = r(N, 2 * d + C, side, side, seed=71)
+    qkv[:, :2 * d] *= 0.6                          # energies of a few units: a soft, not a one-hot, softmax
+    qkv = qkv.to(torch.bfloat16).float()
+    x = r(N, C, side, side, seed=72)
+    dout = r(N, C, side, side, seed=73) * 0.1
+    gamma = torch.tensor([0.7])
+    assert ops.attn_fused_supported(n, d, C) and not ops.attn_fused_supported(n, d, C + 64)
+    # torch reference on [N][n][channels]
+    t = qkv.permute(0, 2, 3, 1).reshape(N, n, -1).clone().requires_grad_(True)
+    xr = x.permute(0, 2, 3, 1).reshape(N, n, C)
+    gr = gamma.clone().requires_grad_(True)
+    q, k, v = t[:, :, :d], t[:, :, d:2 * d], t[:, :, 2 * d:]
+    energy = q @ k.transpose(1, 2)
+    att = torch.softmax(energy, dim=-1)
+    Oref = att @ v
+    out_ref = gr * Oref + xr
+    do = dout.permute(0, 2, 3, 1).reshape(N, n, C)
+    (out_ref * do).sum().backward()
+    # device
+    qv, xv, dv = to_view(qkv), to_view(x), to_view(dout)
+    outv, Ov = ops.new_view(N, side, side, C, DEV), ops.new_view(N, side, side, C, DEV)
+    lse = torch.full((N * n,), float("nan"), device=DEV)
+    gd = gamma.to(DEV)
+    ops.attn_fwd(qv, xv, outv, Ov, lse, gd, d)
+    close(Ov.torch().float().cpu().reshape(N, n, C), Oref.detach(), 1.5e-2, "O")
+    close(outv.torch().float().cpu().reshape(N, n, C), out_ref.detach(), 1.5e-2, "out")
+    assert (lse.cpu().reshape(N, n) - torch.logsumexp(energy.detach(), dim=-1)).abs().max().item() < 1e-3
+    dq = ops.new_view(N, side, side, 2 * d + C, DEV)
+    dq.base.fill_(float("nan"))
+    dgam = torch.full((1,), 2.0, device=DEV)
+    ops.attn_bwd(qv, dq, dv, Ov, lse.data_ptr(), gd, dgam, d)
+    got = dq.torch().float().cpu().reshape(N, n, -1)
+    assert not torch.isnan(got).any()
+    close(got[:, :, 2 * d:], t.grad[:, :, 2 * d:], 3e-2, "dv")
+    close(got[:, :, d:2 * d], t.grad[:, :, d:2 * d], 3e-2, "dk")
+    close(got[:, :, :d], t.grad[:, :, :d], 3e-2, "dq")
+    # dgamma = sum dout * O is a sum of terms of both signs over O rounded to bf16 (2^-9 relative, independent errors)
+    mag = (do * Oref.detach()).abs().sum().item()
+    assert abs(dgam.item() - 2.0 - gr.grad.item()) <= 2e-4 * mag + 1e-3, (dgam.item(), gr.grad.item(), mag)
+    # a sub-range of the images, no gamma gradient (the generator-loss pass through the discriminator)
+    dq.base.fill_(float("nan"))
+    ops.attn_bwd(qv.images(1, 3), dq.images(1, 3), dv.images(1, 3), Ov.images(1, 3), lse.data_ptr() + 4 * n, gd, None, d)
+    got2 = dq.torch().float().cpu().reshape(N, n, -1)
+    assert torch.isnan(got2[0]).all() and torch.equal(got2[1:], got[1:])
