@@ -28,6 +28,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import reid_gan_amd  # noqa: F401  (sets the HIP hardware-queue count before the runtime initialises)
 import torch
 
 PEAK_MFMA_BF16 = 2.5e15        # dense bf16 MFMA peak of one MI355X, FLOP/s

@@ -48,7 +48,7 @@ __device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* lds, int pitch, int kb
 //   qkv [nimg][N][ld]: q in channels [0, D), k in [D, 2D), v in [2D, 2D + C)
 //   O   [nimg][N][ldO] = attention . v (bf16);  out = gamma * O + x;  lse [nimg][N] = log sum_j exp(energy[i][j])
 // ---------------------------------------------------------------------------------------------------------------
-template <int N, int D, int CB>
+template <int N, int D, int CB, bool STAGED>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict__ qkv, long long ld,
                                                        const bf16_t* __restrict__ x, long long ldx,
                                                        bf16_t* __restrict__ out, long long ldo, bf16_t* __restrict__ O,
@@ -99,16 +99,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   f32x4 oacc[CT];
 #pragma unroll
   for (int ct = 0; ct < CT; ++ct) oacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // the next chunk of v travels global -> registers while the current one is multiplied
+  u32x4 pv[CB / 32];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int u = 0; u < CB / 32; ++u) {
+      const int idx = tid + 256 * u, key = idx / (CB / 8), c8 = (idx % (CB / 8)) * 8;
+      pv[u] = *reinterpret_cast<const u32x4*>(base + (long long)(kc * 64 + key) * ld + 2 * D + c0 + c8);
+    }
+  };
+  fetch(0);
 #pragma unroll
   for (int kc = 0; kc < NKC; ++kc) {
     if (kc) __syncthreads();
 #pragma unroll
     for (int u = 0; u < CB / 32; ++u) {
       const int idx = tid + 256 * u, key = idx / (CB / 8), c8 = (idx % (CB / 8)) * 8;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(base + (long long)(kc * 64 + key) * ld + 2 * D + c0 + c8);
-      *reinterpret_cast<u32x4*>(vl + key * CB + (c8 ^ attn_swz(key))) = v;
+      *reinterpret_cast<u32x4*>(vl + key * CB + (c8 ^ attn_swz(key))) = pv[u];
     }
     __syncthreads();
+    if (kc + 1 < NKC) fetch(kc + 1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const bf16x8_t b = pack_pair(acc[kc * 4 + 2 * ks], acc[kc * 4 + 2 * ks + 1]);
@@ -116,18 +126,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
       for (int ct = 0; ct < CT; ++ct) oacc[ct] = mfma16(tr_frag<true, true>(vl, CB, 32 * ks, 16 * ct, lane), b, oacc[ct]);
     }
   }
-  const float gam = gamma[0];
-  const long long row = img * N + q0 + l;
+  if constexpr (!STAGED) {
+    const float gam = gamma[0];
+    const long long row = img * N + q0 + l;
 #pragma unroll
-  for (int ct = 0; ct < CT; ++ct) {
-    const int ch = c0 + 16 * ct + 4 * g;
-    const u32x2 ob = {pack2bf(oacc[ct][0], oacc[ct][1]), pack2bf(oacc[ct][2], oacc[ct][3])};
-    *reinterpret_cast<u32x2*>(O + row * ldO + ch) = ob;
-    const u32x2 xr = *reinterpret_cast<const u32x2*>(x + row * ldx + ch);
+    for (int ct = 0; ct < CT; ++ct) {
+      const int ch = c0 + 16 * ct + 4 * g;
+      const u32x2 ob = {pack2bf(oacc[ct][0], oacc[ct][1]), pack2bf(oacc[ct][2], oacc[ct][3])};
+      *reinterpret_cast<u32x2*>(O + row * ldO + ch) = ob;
+      const u32x2 xr = *reinterpret_cast<const u32x2*>(x + row * ldx + ch);
+      *reinterpret_cast<u32x2*>(out + row * ldo + ch) =
+          u32x2{pack2bf(gam * bflo(ob[0]) + bflo(xr[0]), gam * bfhi(ob[0]) + bfhi(xr[0])),
+                pack2bf(gam * bflo(ob[1]) + bflo(xr[1]), gam * bfhi(ob[1]) + bfhi(xr[1]))};
+    }
+    return;
+  }
+  // Epilogue through LDS: in the MFMA layout a lane owns 4 channels of one query (8-byte pieces of 16 rows per
+  // instruction); staged, 32 consecutive lanes read and write one contiguous 512-byte row of O, x and out.
+  constexpr int PO = CB + 8;
+  bf16_t* ol = vl + wave * 16 * PO;                           // this wave's [16 queries][PO]
+  __syncthreads();                                            // every wave has read the last chunk of v
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+    *reinterpret_cast<u32x2*>(ol + l * PO + 16 * ct + 4 * g) =
+        u32x2{pack2bf(oacc[ct][0], oacc[ct][1]), pack2bf(oacc[ct][2], oacc[ct][3])};
+  const float gam = gamma[0];
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 16 * (CB / 8) / 64; ++u) {
+    const int idx = lane + 64 * u, r = idx / (CB / 8), c8 = (idx % (CB / 8)) * 8;
+    const long long row = img * N + q0 + r;
+    const u32x4 ob = *reinterpret_cast<const u32x4*>(ol + r * PO + c8);
+    const u32x4 xr = *reinterpret_cast<const u32x4*>(x + row * ldx + c0 + c8);
+    *reinterpret_cast<u32x4*>(O + row * ldO + c0 + c8) = ob;
+    u32x4 o;
     // (the stored, rounded O enters the residual sum, as it does when the two steps are separate kernels)
-    *reinterpret_cast<u32x2*>(out + row * ldo + ch) =
-        u32x2{pack2bf(gam * bflo(ob[0]) + bflo(xr[0]), gam * bfhi(ob[0]) + bfhi(xr[0])),
-              pack2bf(gam * bflo(ob[1]) + bflo(xr[1]), gam * bfhi(ob[1]) + bfhi(xr[1]))};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = pack2bf(gam * bflo(ob[k]) + bflo(xr[k]), gam * bfhi(ob[k]) + bfhi(xr[k]));
+    *reinterpret_cast<u32x4*>(out + row * ldo + c0 + c8) = o;
   }
 }
 
@@ -150,7 +186,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   bf16_t* dOl = reinterpret_cast<bf16_t*>(attn_smem);        // [64 queries][C], swizzled
   bf16_t* Ql = dOl + 64 * C;                                  // [64 queries][PQ]
   bf16_t* Kl = Ql + 64 * PQ;                                  // [64 keys][PQ]
-  bf16_t* dSl = Kl + 64 * PQ;                                 // [64 queries][PS]
+  bf16_t* dSl = Kl + 64 * PQ;                                 // [64 keys][PS] (queries along the row)
   float* Dq = reinterpret_cast<float*>(dSl + 64 * PS);        // [N]
   float* lsel = Dq + N;                                       // [N]
   float* red = lsel + N;                                      // [4]
@@ -212,21 +248,37 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
       *reinterpret_cast<u32x4*>(Kl + r * PQ + c8) =
           *reinterpret_cast<const u32x4*>(base + (long long)(jb * 64 + r) * ld + D + c8);
     }
+    // The next query block's dout and q rows travel global -> registers while the current block is computed.
+    constexpr int NDO = C / 32, NQ = (64 * D / 8 + 255) / 256;
+    u32x4 pdo[NDO], pq[NQ];
+    auto fetch = [&](int ib) {
+#pragma unroll
+      for (int u = 0; u < NDO; ++u) {
+        const int idx = tid + 256 * u, r = idx / (C / 8), c8 = (idx % (C / 8)) * 8;
+        pdo[u] = *reinterpret_cast<const u32x4*>(dob + (long long)(ib * 64 + r) * lddo + c8);
+      }
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int idx = tid + 256 * u, r = idx / (D / 8), c8 = (idx % (D / 8)) * 8;
+        if (idx < 64 * D / 8) pq[u] = *reinterpret_cast<const u32x4*>(base + (long long)(ib * 64 + r) * ld + c8);
+      }
+    };
+    fetch(0);
 #pragma unroll
     for (int ib = 0; ib < NB; ++ib) {
       // stage this query block: dout rows (swizzled) and q rows
 #pragma unroll
-      for (int u = 0; u < C / 32; ++u) {
+      for (int u = 0; u < NDO; ++u) {
         const int idx = tid + 256 * u, r = idx / (C / 8), c8 = (idx % (C / 8)) * 8;
-        *reinterpret_cast<u32x4*>(dOl + r * C + (c8 ^ attn_swz(r))) =
-            *reinterpret_cast<const u32x4*>(dob + (long long)(ib * 64 + r) * lddo + c8);
+        *reinterpret_cast<u32x4*>(dOl + r * C + (c8 ^ attn_swz(r))) = pdo[u];
       }
-      for (int idx = tid; idx < 64 * D / 8; idx += 256) {
-        const int r = idx / (D / 8), c8 = (idx % (D / 8)) * 8;
-        *reinterpret_cast<u32x4*>(Ql + r * PQ + c8) =
-            *reinterpret_cast<const u32x4*>(base + (long long)(ib * 64 + r) * ld + c8);
+#pragma unroll
+      for (int u = 0; u < NQ; ++u) {
+        const int idx = tid + 256 * u, r = idx / (D / 8), c8 = (idx % (D / 8)) * 8;
+        if (idx < 64 * D / 8) *reinterpret_cast<u32x4*>(Ql + r * PQ + c8) = pq[u];
       }
       __syncthreads();
+      if (ib + 1 < NB) fetch(ib + 1);
       // energy and dP tiles: D[i = query 16t + 4g + r][j = key]
       f32x4 s[4], dp[4];
 #pragma unroll
@@ -248,16 +300,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
         }
       }
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        const int q = 16 * t + 4 * g;
+        const f32x4 ls = *reinterpret_cast<const f32x4*>(lsel + ib * 64 + q);
+        const f32x4 dq4 = *reinterpret_cast<const f32x4*>(Dq + ib * 64 + q);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = 16 * t + 4 * g + r, gq = ib * 64 + q;
-          const float p = __expf(s[t][r] - lsel[gq]);
-          const float ds = gam * p * (dp[t][r] - Dq[gq]);
+          const float p = __expf(s[t][r] - ls[r]);
+          dp[t][r] = gam * p * (dp[t][r] - dq4[r]);
           s[t][r] = p;
-          dp[t][r] = ds;
-          dSl[q * PS + wave * 16 + l] = f2bf(ds);
         }
+        // dS^T image: row = this lane's key, four consecutive queries
+        *reinterpret_cast<u32x2*>(dSl + (wave * 16 + l) * PS + q) =
+            u32x2{pack2bf(dp[t][0], dp[t][1]), pack2bf(dp[t][2], dp[t][3])};
+      }
       // contractions over the 64 queries: dv^T and dk^T for this wave's keys
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -271,10 +327,11 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
           dKacc[et] = mfma16(tr_frag<false, true>(Ql, PQ, 32 * h, 16 * et, lane), bs, dKacc[et]);
       }
       __syncthreads();
-      // dq^T for this wave's queries: D[i = e][j = query] = sum_key k[key][e] dS[query][key]
+      // dq^T for this wave's queries: D[i = e][j = query] = sum_key k[key][e] dS[query][key]; both operands are
+      // [key][.] images read through the transposing load
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const bf16x8_t b = ld_frag(dSl + (wave * 16 + l) * PS + h * 32 + 8 * g);
+        const bf16x8_t b = tr_frag<false, false>(dSl, PS, 32 * h, 16 * wave, lane);
 #pragma unroll
         for (int et = 0; et < ET; ++et)
           dQacc[ib][et] = mfma16(tr_frag<false, false>(Kl, PQ, 32 * h, 16 * et, lane), b, dQacc[ib][et]);
@@ -335,13 +392,13 @@ extern "C" int ried_attn_fwd(const void* qkv, long long ld, const void* x, long 
   RIED_CHECK_ARG(aligned_view(x, ldx, C) && aligned_view(out, ldo, C) && aligned_view(O, ldO, C) && lse && gamma,
                  "ried_attn_fwd: bad view");
   constexpr int CB = 256;
-  const size_t sh = 64 * CB * sizeof(bf16_t);
+  const size_t sh = 64 * (CB + 8) * sizeof(bf16_t);       // the v chunk, then the staged output rows
   dim3 grid(n / 64, nimg, C / CB);
   if (n == 256)
-    hipLaunchKernelGGL((attn_fwd_kernel<256, 32, CB>), grid, dim3(256), sh, stream, (const bf16_t*)qkv, ld,
+    hipLaunchKernelGGL((attn_fwd_kernel<256, 32, CB, false>), grid, dim3(256), sh, stream, (const bf16_t*)qkv, ld,
                        (const bf16_t*)x, ldx, (bf16_t*)out, ldo, (bf16_t*)O, ldO, lse, gamma);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<64, 64, CB>), grid, dim3(256), sh, stream, (const bf16_t*)qkv, ld,
+    hipLaunchKernelGGL((attn_fwd_kernel<64, 64, CB, true>), grid, dim3(256), sh, stream, (const bf16_t*)qkv, ld,
                        (const bf16_t*)x, ldx, (bf16_t*)out, ldo, (bf16_t*)O, ldO, lse, gamma);
   RIED_CHECK_LAUNCH("ried_attn_fwd");
   return RIED_OK;
