@@ -108,7 +108,10 @@ int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp, int Cg, f
  * row of 64-bit words holding pointers and integers; blockmap[b] = (job, chunk): for pack jobs block b handles
  * elements [2048*chunk, 2048*(chunk+1)) of its job, for reduce jobs the output row p = chunk (Cp blocks per job).
  *   pack job (13 words): src, dst, sigma|0, N, R, S, C, sn, sr, ss, sc, dst_pitch, dst_f32 - as ried_pack_weight,
- *     with dst[n*dst_pitch + (r*S+s)*C + c]; dst is fp32 instead of bf16 when dst_f32 != 0.
+ *     with dst[n*dst_pitch + (r*S+s)*C + c]; dst is fp32 instead of bf16 when dst_f32 == 1.
+ *     dst_f32 == 2, a tile job: words src, dst1, sigma, A, B, T, dst2 - the master is [A][B][T] (T <= 16; A, B even)
+ *     and is written as dst1 [A][T][B] and dst2 [B][T][A] (bf16, either may be 0): both packed layouts of a
+ *     convolution weight from one read of it; blockmap chunk = tile (a / 32) * ceil(B / 32) + b / 32.
  *   reduce job (11 words): slab, out, splitk, split_stride, taps, Cp, Cg, st, sp, sg, accumulate - as
  *     ried_wgrad_reduce with scale 1 and slab[k*split_stride + (tap*Cp + p)*Cg + g]. */
 int ried_pack_jobs(const long long* jobs, const int* blockmap, int nblocks, ried_stream_t stream);

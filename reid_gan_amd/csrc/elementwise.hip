@@ -98,12 +98,51 @@ extern "C" int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp
 // ---------------------------------------------------------------------------
 #define JOB_CHUNK 2048
 #define PACK_JOB_WORDS 13
+#define PACK_TILE_MAX_T 16
+#define PACK_TILE_PITCH (32 * PACK_TILE_MAX_T + 2)
 // pack job: src, dst, sigma, N, R, S, C, sn, sr, ss, sc, dst_pitch, dst_f32
 __global__ __launch_bounds__(256) void pack_jobs_kernel(const long long* __restrict__ jobs,
                                                         const int* __restrict__ blockmap) {
   const long long* J = jobs + (long long)blockmap[2 * blockIdx.x] * PACK_JOB_WORDS;
   const float* src = (const float*)J[0];
   const float* sigma = (const float*)J[2];
+  if (J[12] == 2) {
+    // Tile job: a master stored [A][B][T] (a conv weight (Cout, Cin, kh*kw) or a transposed conv's (Cin, Cout, kh*kw))
+    // -> dst1 [A][T][B] and dst2 [B][T][A] (either may be null), bf16, divided by sigma.  One block moves a tile of
+    // 32 a x 32 b x all T through LDS: the master is read in contiguous runs of 32 T floats and both layouts are
+    // written in contiguous 64-byte runs, where the strided form reads one float per cache line for the
+    // transposed layout.
+    __shared__ bf16_t tile[32][PACK_TILE_PITCH];
+    const int A = (int)J[3], B = (int)J[4], T = (int)J[5];
+    bf16_t* d1 = (bf16_t*)J[1];
+    bf16_t* d2 = (bf16_t*)J[6];
+    const int tilesB = (B + 31) >> 5, chunk = blockmap[2 * blockIdx.x + 1];
+    const int a0 = (chunk / tilesB) << 5, b0 = (chunk % tilesB) << 5;
+    const int na = min(32, A - a0), nb = min(32, B - b0), run = nb * T;
+    const float inv = sigma ? 1.f / sigma[0] : 1.f;
+    for (int idx = threadIdx.x; idx < na * run; idx += 256) {
+      const int a = idx / run, j = idx - a * run;
+      tile[a][j] = f2bf(src[((long long)(a0 + a) * B + b0) * T + j] * inv);
+    }
+    __syncthreads();
+    if (d1) {       // [a][t][b]: pairs of b
+      const int hb = nb >> 1;
+      for (int idx = threadIdx.x; idx < na * T * hb; idx += 256) {
+        const int b2 = idx % hb, at = idx / hb, t = at % T, a = at / T;
+        const unsigned v = (unsigned)tile[a][(2 * b2) * T + t] | ((unsigned)tile[a][(2 * b2 + 1) * T + t] << 16);
+        *reinterpret_cast<unsigned*>(d1 + ((long long)(a0 + a) * T + t) * B + b0 + 2 * b2) = v;
+      }
+    }
+    if (d2) {       // [b][t][a]: pairs of a
+      const int ha = na >> 1;
+      for (int idx = threadIdx.x; idx < nb * T * ha; idx += 256) {
+        const int a2 = idx % ha, bt = idx / ha, t = bt % T, b = bt / T;
+        const unsigned v = (unsigned)tile[2 * a2][b * T + t] | ((unsigned)tile[2 * a2 + 1][b * T + t] << 16);
+        *reinterpret_cast<unsigned*>(d2 + ((long long)(b0 + b) * T + t) * A + a0 + 2 * a2) = v;
+      }
+    }
+    return;
+  }
   const int R = (int)J[4], S = (int)J[5], C = (int)J[6];
   const long long sn = J[7], sr = J[8], ss = J[9], sc = J[10], pitch = J[11];
   const long long inner = (long long)R * S * C, total = J[3] * inner;

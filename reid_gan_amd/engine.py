@@ -187,6 +187,14 @@ class Ctx:
                         sn, sr, ss, sc, R * S * C if dst_pitch is None else dst_pitch,
                         1 if dst.dtype == F32 else 0], N * R * S * C)
 
+    def add_pack_pair(self, src: torch.Tensor, dst1: Optional[torch.Tensor], dst2: Optional[torch.Tensor], A, B, T,
+                      sigma=None):
+        """Master [A][B][T] -> dst1 [A][T][B] and dst2 [B][T][A] (bf16, / sigma) from one read of it (a tile job)."""
+        assert T <= 16 and A % 2 == 0 and B % 2 == 0
+        self.packs.add([src.data_ptr(), 0 if dst1 is None else dst1.data_ptr(), 0 if sigma is None else sigma.data_ptr(),
+                        A, B, T, 0 if dst2 is None else dst2.data_ptr(), 0, 0, 0, 0, 0, 2],
+                       nblocks=((A + 31) // 32) * ((B + 31) // 32))
+
     def add_wgrad_reduce(self, slab_off, out: torch.Tensor, splitk, taps, Cp, Cg, st, sp, sg, accumulate=False):
         j = self.wreds.add([0, out.data_ptr(), splitk, taps * Cp * Cg, taps, Cp, Cg, st, sp, sg, int(accumulate)],
                            nblocks=Cp)
@@ -387,7 +395,12 @@ class ConvCore:
                 ctx.add_wgrad_reduce(self.slab_off, out, self.splitk, taps, cout, cin, 1, cin * taps, taps)
         if ctx.st is not None:
             w, t, kh, kw = ctx.st.p[wname], taps, self.kh, self.kw
-            if deconv:    # master (Cin,Cout,kh,kw) -> [Cout][kh][kw][Cin]; backward layout [Cin][kh][kw][Cout]
+            if t <= 16 and cin % 2 == 0 and cout % 2 == 0 and PACK_TILES:     # both layouts from one read of the master
+                if deconv:
+                    ctx.add_pack_pair(w, self.wpt, self.wp, cin, cout, t, sigma)
+                else:
+                    ctx.add_pack_pair(w, self.wp, self.wpt, cout, cin, t, sigma)
+            elif deconv:  # master (Cin,Cout,kh,kw) -> [Cout][kh][kw][Cin]; backward layout [Cin][kh][kw][Cout]
                 ctx.add_pack(w, self.wp, cout, kh, kw, cin, t, kw, 1, cout * t, sigma)
                 if self.wpt is not None:
                     ctx.add_pack(w, self.wpt, cin, kh, kw, cout, cout * t, kw, 1, t, sigma)
@@ -701,6 +714,7 @@ class InputGradGroup:
 
 SIBLING_GROUPS = not os.environ.get("RIED_NO_SIBLING_GROUPS")      # switch for A/B runs and tests
 FUSED_ATTN = not os.environ.get("RIED_NO_FUSED_ATTN")
+PACK_TILES = not os.environ.get("RIED_NO_PACK_TILES")
 FWD_BN_JOBS = not os.environ.get("RIED_NO_FWD_BN_JOBS")
 
 
