@@ -120,25 +120,29 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const long long* __restr
     const int a0 = (chunk / tilesB) << 5, b0 = (chunk % tilesB) << 5;
     const int na = min(32, A - a0), nb = min(32, B - b0), run = nb * T;
     const float inv = sigma ? 1.f / sigma[0] : 1.f;
-    for (int idx = threadIdx.x; idx < na * run; idx += 256) {
-      const int a = idx / run, j = idx - a * run;
-      tile[a][j] = f2bf(src[((long long)(a0 + a) * B + b0) * T + j] * inv);
+    // (no integer divisions in the loops: a wave walks whole rows; the (a, t) of a row comes from a float reciprocal)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int a = wave; a < na; a += 4) {
+      const float* row = src + ((long long)(a0 + a) * B + b0) * T;
+      for (int j = lane; j < run; j += 64) tile[a][j] = f2bf(row[j] * inv);
     }
     __syncthreads();
-    if (d1) {       // [a][t][b]: pairs of b
-      const int hb = nb >> 1;
-      for (int idx = threadIdx.x; idx < na * T * hb; idx += 256) {
-        const int b2 = idx % hb, at = idx / hb, t = at % T, a = at / T;
-        const unsigned v = (unsigned)tile[a][(2 * b2) * T + t] | ((unsigned)tile[a][(2 * b2 + 1) * T + t] << 16);
-        *reinterpret_cast<unsigned*>(d1 + ((long long)(a0 + a) * T + t) * B + b0 + 2 * b2) = v;
+    const float invT = 1.f / (float)T;
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;      // 16 lanes per output row of 32 elements
+    if (d1 && sub < (nb >> 1)) {       // [a][t][b]: pairs of b
+      for (int r = grp; r < na * T; r += 16) {
+        int t;
+        const int a = fast_div(r, T, invT, t);
+        const unsigned v = (unsigned)tile[a][(2 * sub) * T + t] | ((unsigned)tile[a][(2 * sub + 1) * T + t] << 16);
+        *reinterpret_cast<unsigned*>(d1 + ((long long)(a0 + a) * T + t) * B + b0 + 2 * sub) = v;
       }
     }
-    if (d2) {       // [b][t][a]: pairs of a
-      const int ha = na >> 1;
-      for (int idx = threadIdx.x; idx < nb * T * ha; idx += 256) {
-        const int a2 = idx % ha, bt = idx / ha, t = bt % T, b = bt / T;
-        const unsigned v = (unsigned)tile[2 * a2][b * T + t] | ((unsigned)tile[2 * a2 + 1][b * T + t] << 16);
-        *reinterpret_cast<unsigned*>(d2 + ((long long)(b0 + b) * T + t) * A + a0 + 2 * a2) = v;
+    if (d2 && sub < (na >> 1)) {       // [b][t][a]: pairs of a
+      for (int r = grp; r < nb * T; r += 16) {
+        int t;
+        const int b = fast_div(r, T, invT, t);
+        const unsigned v = (unsigned)tile[2 * sub][b * T + t] | ((unsigned)tile[2 * sub + 1][b * T + t] << 16);
+        *reinterpret_cast<unsigned*>(d2 + ((long long)(b0 + b) * T + t) * A + a0 + 2 * sub) = v;
       }
     }
     return;
