@@ -92,8 +92,8 @@ def instrumented_step(ts):
     launch_jobs = ops.WgradJobs.launch           # the grouped weight-gradient launches of the generator
     ops.WgradJobs.launch = wrap("wgrad", launch_jobs, lambda self: self.flops)
     # kernels timed one at a time: no side streams while the events are in place
-    saved = (ts.overlap_vgg, ts.overlap_gbwd, os.environ.get("RIED_SERIAL_BRANCHES"))
-    ts.overlap_vgg = ts.overlap_gbwd = False
+    saved = (ts.overlap_vgg, ts.overlap_gbwd, os.environ.get("RIED_SERIAL_BRANCHES"), ts.overlap_dreal)
+    ts.overlap_vgg = ts.overlap_gbwd = ts.overlap_dreal = False
     os.environ["RIED_SERIAL_BRANCHES"] = "1"
     try:
         # An event pair also spans the time the GPU waits for the host to submit the launch between them, so the
@@ -109,7 +109,7 @@ def instrumented_step(ts):
         for k, v in orig.items():
             setattr(ops, k, v)
         ops.WgradJobs.launch = launch_jobs
-        ts.overlap_vgg, ts.overlap_gbwd = saved[0], saved[1]
+        ts.overlap_vgg, ts.overlap_gbwd, ts.overlap_dreal = saved[0], saved[1], saved[3]
         if saved[2] is None:
             del os.environ["RIED_SERIAL_BRANCHES"]
         else:

@@ -409,8 +409,8 @@ class ConvCore:
                 if self.wpt is not None:
                     ctx.add_pack(w, self.wpt, cin, kh, kw, cout, t, kw, 1, cin * t, sigma)
 
-    def conv(self, y: View, **kw):
-        ops.conv2d(self.xin.v, self.wp, y, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
+    def conv(self, y: View, x: Optional[View] = None, **kw):
+        ops.conv2d(self.xin.v if x is None else x, self.wp, y, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
                    transposed=self.deconv, **kw)
 
     def dgrad(self, dy: View, dx: View, accumulate=True, **kw):
@@ -1214,14 +1214,17 @@ class SNConv:
                    cout, self.K, self.dwsn, st.g[prefix + ".weight_orig"] if ctx.grads else None)
         self.x_img: Optional[torch.Tensor] = None
 
-    def forward(self, x_img: Optional[torch.Tensor] = None):
+    def forward(self, x_img: Optional[torch.Tensor] = None, n0: int = 0, n1: Optional[int] = None):
+        """Images [n0, n1) only (the layer has no statistics across the batch: halves may run at different times)."""
         st, p = self.ctx.st, self.prefix
+        n1 = self.out.shape[0] if n1 is None else n1
+        out = self.out.images(n0, n1).v
         if self.first:
             self.x_img = x_img
-            ops.conv_c1_fwd(x_img, st.p[p + ".weight_orig"], self.out.v, self.stride, sigma=self.sigma,
+            ops.conv_c1_fwd(x_img[n0:n1], st.p[p + ".weight_orig"], out, self.stride, sigma=self.sigma,
                             bias=st.p[p + ".bias"], act=2)
         else:
-            self.core.conv(self.out.v, bias=st.p[p + ".bias"], act=2)
+            self.core.conv(out, x=self.core.xin.images(n0, n1).v, bias=st.p[p + ".bias"], act=2)
 
     def backward(self, n0: int, n1: int, wgrad: bool, dimg: Optional[torch.Tensor] = None):
         """Images [n0, n1) only.  wgrad: parameter gradients; dimg (first layer): fp32 image gradient, +=."""
@@ -1306,13 +1309,17 @@ class Attn:
         return [(p + ".query_conv", 0, self.d), (p + ".key_conv", self.d, 2 * self.d),
                 (p + ".value_conv", 2 * self.d, self.cq)]
 
-    def forward(self):
+    def forward(self, n0: int = 0, n1: Optional[int] = None):
         st, C, d, n, N = self.ctx.st, self.C, self.d, self.n, self.N
+        if self.fused:        # per image: any range of the batch
+            n1 = N if n1 is None else n1
+            x, qkv = self.xin.images(n0, n1).v, self.qkv.images(n0, n1).v
+            ops.conv2d(x, self.wp, qkv, 1, 1, 1, 1, 0, 0, bias=self.bias)
+            ops.attn_fwd(qkv, x, self.out.images(n0, n1).v, self.O.images(n0, n1), self.lse[n0 * n:], st.p[self.prefix + ".gamma"], d)
+            return
+        assert n0 == 0 and n1 in (None, N), "the unfused attention path runs the whole batch"
         x, qkv = self.xin.v, self.qkv.v
         ops.conv2d(x, self.wp, qkv, 1, 1, 1, 1, 0, 0, bias=self.bias)
-        if self.fused:
-            ops.attn_fwd(qkv, x, self.out.v, self.O, self.lse, st.p[self.prefix + ".gamma"], d)
-            return
         q, k, v = qkv.ptr, qkv.ptr + 2 * d, qkv.ptr + 4 * d
         ld, bs = qkv.ld, n * qkv.ld
         # S[b][i][j] = q_i . k_j : m = j (A = k), n = i (B = q)
@@ -1415,14 +1422,31 @@ class Discriminator:
 
     def forward(self, x_img: torch.Tensor) -> Slot:
         """x_img: fp32 (N,1,H,W).  Returns the last activation (N, H/16, W/16, 512) NHWC bf16."""
-        assert x_img.shape == (self.N, 1, self.H, self.W) and x_img.dtype == F32 and x_img.is_contiguous()
+        self.prepare()
+        return self.forward_images(x_img, 0, self.N)
+
+    @property
+    def splittable(self) -> bool:
+        """True if forward_images() accepts a sub-range of the batch."""
+        return all(l.fused for l in self.layers if isinstance(l, Attn))
+
+    def prepare(self):
+        """The part of a forward pass that depends on the weights only: one power iteration per spectral-norm layer
+        (src/rinet.py:138 runs it in every training-mode forward), sigma, and the packed W / sigma."""
         self.ctx.sn_sigmas()
         self.ctx.begin_forward()
+
+    def forward_images(self, x_img: torch.Tensor, n0: int, n1: int) -> Slot:
+        """The layers on images [n0, n1) of x_img (N,1,H,W), after prepare().  No layer couples the images of a batch
+        (no BatchNorm; attention is per image), so ranges may run at different times and on different streams."""
+        assert x_img.shape == (self.N, 1, self.H, self.W) and x_img.dtype == F32 and x_img.is_contiguous()
         for i, l in enumerate(self.layers):
             if i == 0:
-                l.forward(x_img)
+                l.forward(x_img, n0, n1)
+            elif isinstance(l, SNConv):
+                l.forward(None, n0, n1)
             else:
-                l.forward()
+                l.forward(n0, n1)
         return self.acts[-1]
 
     def backward(self, n0: int, n1: int, wgrad: bool, dimg: Optional[torch.Tensor] = None):
