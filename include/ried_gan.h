@@ -306,8 +306,9 @@ int ried_mse_tap(const void* a, const void* b, long long n, float loss_scale, fl
  * loss[0] += loss_scale * sum_p ||a[p]-b[p]||_2; g (bf16 [npix][C], may be NULL) = grad_scale*(a-b)/||a[p]-b[p]|| */
 int ried_l2norm_tap(const void* a, const void* b, long long npix, int C, float loss_scale, float* loss, void* g,
                     float grad_scale, ried_stream_t stream);
-/* DLoss (src/loss.py:141-142): sc[0]=mean(pos), sc[1]=mean(neg) -> sc[2]=loss, sc[3], sc[4] = per-element gradients */
-int ried_dloss_scalars(float* sc, long long n_per_half, ried_stream_t stream);
+/* DLoss (src/loss.py:141-142): sc[0]=mean(pos), sc[1]=mean(neg) -> sc[2]=loss, sc[3], sc[4] = per-element gradients;
+ * keep (may be NULL): keep[0] = loss as well */
+int ried_dloss_scalars(float* sc, long long n_per_half, float* keep, ried_stream_t stream);
 /* CompoundLoss weighting (src/loss.py:191-194): sc[1], sc[5]=vgg, sc[6]=ssim -> sc[7]=dssim, sc[8]=gen, sc[9]=loss */
 int ried_gloss_scalars(float* sc, float wv, float ws, float wg, ried_stream_t stream);
 

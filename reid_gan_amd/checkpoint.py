@@ -116,11 +116,16 @@ def load_checkpoint(path: str) -> dict:
 
 def restore(ts, ck: dict, optimizers: bool = True) -> dict:
     """Put a loaded checkpoint into a TrainStep (networks, and Adam state when present and wanted).  Returns
-    {'epoch', 'total_iters', 'lr'} as stored."""
+    {'epoch', 'total_iters', 'lr'} as stored.  With the optimizer state comes the learning rate the optimizers
+    were saved with (param_groups[0]['lr'] of optG_state_dict: torch's load_state_dict restores it the same way,
+    train.py:91-92); the top-level 'lr' entry is only reported, as in the reference (train.py:94,97)."""
     load_net_state(ts.gs, ck["netG_state_dict"])
     if "netD_state_dict" in ck:
         load_net_state(ts.ds, ck["netD_state_dict"])
     if optimizers and "optG_state_dict" in ck:
         load_optim_state(ts.gs, "G", ck["optG_state_dict"])
         load_optim_state(ts.ds, "D", ck["optD_state_dict"])
+        groups = ck["optG_state_dict"].get("param_groups") or []
+        if groups and "lr" in groups[0]:
+            ts.lr = float(groups[0]["lr"])
     return {k: ck.get(k) for k in ("epoch", "total_iters", "lr")}

@@ -785,18 +785,20 @@ extern "C" int ried_l2norm_tap(const void* a, const void* b, long long npix, int
 //  in : sc[0] = mean(pos)  sc[1] = mean(neg)
 //  out: sc[2] = dloss = relu(1-mean(pos)) + relu(1+mean(neg))
 //       sc[3] = d dloss / d pos_i = -[1-mean(pos) > 0]/n     sc[4] = d dloss / d neg_i = +[1+mean(neg) > 0]/n
+//       keep[0] = dloss too when keep is given (the step keeps both iterations' values)
 // ---------------------------------------------------------------------------
-__global__ void dloss_scalars_kernel(float* sc, float inv_n) {
+__global__ void dloss_scalars_kernel(float* sc, float inv_n, float* keep) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float a = 1.f - sc[0], b = 1.f + sc[1];
     sc[2] = fmaxf(a, 0.f) + fmaxf(b, 0.f);
+    if (keep) keep[0] = sc[2];
     sc[3] = a > 0.f ? -inv_n : 0.f;
     sc[4] = b > 0.f ? inv_n : 0.f;
   }
 }
-extern "C" int ried_dloss_scalars(float* sc, long long n_per_half, hipStream_t stream) {
+extern "C" int ried_dloss_scalars(float* sc, long long n_per_half, float* keep, hipStream_t stream) {
   RIED_CHECK_ARG(sc && n_per_half > 0, "ried_dloss_scalars: bad arguments");
-  hipLaunchKernelGGL(dloss_scalars_kernel, dim3(1), dim3(64), 0, stream, sc, 1.f / (float)n_per_half);
+  hipLaunchKernelGGL(dloss_scalars_kernel, dim3(1), dim3(64), 0, stream, sc, 1.f / (float)n_per_half, keep);
   RIED_CHECK_LAUNCH("ried_dloss_scalars");
   return RIED_OK;
 }

@@ -1529,12 +1529,15 @@ class Vgg:
         ctx.finalize()
         torch.cuda.synchronize()
 
-    def forward(self, imgs: torch.Tensor, n0: int = 0, n1: Optional[int] = None):
+    def forward(self, imgs: torch.Tensor, n0: int = 0, n1: Optional[int] = None, src0: Optional[int] = None):
         """imgs: fp32 (2B,1,H,W): prediction images first, then targets.  Only images [n0, n1) are processed, so
-        the target half can run early, beside other work, and the prediction half once it exists."""
+        the target half can run early, beside other work, and the prediction half once it exists.  With src0 the
+        images are read from imgs[src0 : src0 + n1 - n0] instead (a tensor that holds only one of the halves)."""
         n1 = 2 * self.B if n1 is None else n1
         a0 = self.a0.images(n0, n1)
-        ops.conv_c1_fwd(imgs[n0:n1], self.w0, a0.v, 1, bias=self.b0, in_scale=self.in_scale, in_shift=self.in_shift, act=1)
+        src = imgs[n0:n1] if src0 is None else imgs[src0:src0 + n1 - n0]
+        assert src.shape[0] == n1 - n0 and src.is_contiguous()
+        ops.conv_c1_fwd(src, self.w0, a0.v, 1, bias=self.b0, in_scale=self.in_scale, in_shift=self.in_shift, act=1)
         for l in self.layers:
             if l[0] == "pool":
                 p = l[1]

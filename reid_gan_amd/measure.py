@@ -83,7 +83,10 @@ def compute_RMSE(img1, img2):
 
 
 def compute_PSNR(img1, img2, data_range):
-    return 10 * math.log10((data_range ** 2) / compute_MSE(img1, img2))     # src/measure.py:29-35
+    mse = compute_MSE(img1, img2)
+    if mse == 0:                         # identical images: log10 of a division by zero (src/measure.py:31-32)
+        return float("inf")
+    return 10 * math.log10((data_range ** 2) / mse)     # src/measure.py:29-35
 
 
 def compute_SSIM(img1, img2, data_range, window_size=11, channel=1, size_average=True):

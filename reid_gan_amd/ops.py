@@ -506,8 +506,8 @@ def mse_tap(a_ptr, b_ptr, n, loss_scale, loss, g_ptr, grad_scale, accumulate=Fal
     lib.ried_mse_tap(a_ptr, b_ptr, n, loss_scale, _p(loss), g_ptr, grad_scale, int(accumulate), _stream())
 
 
-def dloss_scalars(sc: torch.Tensor, n_per_half: int):
-    lib.ried_dloss_scalars(_p(sc), n_per_half, _stream())
+def dloss_scalars(sc: torch.Tensor, n_per_half: int, keep: Optional[torch.Tensor] = None):
+    lib.ried_dloss_scalars(_p(sc), n_per_half, _p(keep) if keep is not None else None, _stream())
 
 
 def gloss_scalars(sc: torch.Tensor, wv, ws, wg):

@@ -46,17 +46,30 @@ def bind_state(module: nn.Module, key_prefix: str = "") -> State:
     return st
 
 
+def _check_serial(plan, serial: int, what: str):
+    """A plan keeps the activations of its LAST forward only: a backward that belongs to an earlier forward of the
+    same module and input shape would silently use the later call's activations, so it is refused."""
+    if plan.serial != serial:
+        raise RuntimeError(
+            f"{what}: backward of forward call #{serial}, but the module has since run forward call #{plan.serial} "
+            "with the same input shape; the plan holds one set of activations per shape. Run backward before the "
+            "next forward of that shape, or batch the inputs into one call (as the reference's training loop does).")
+
+
 class _PlanFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, x, *params):
         runner = module._runner(x)
         ctx.runner = runner
         ctx.need_dx = x.requires_grad
-        return runner.forward(x)
+        y = runner.forward(x)
+        ctx.serial = runner.serial
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         r = ctx.runner
+        _check_serial(r, ctx.serial, type(r.module).__name__)
         dx = r.backward(dy.contiguous(), ctx.need_dx)
         grads = [r.state.g[r.key_prefix + k].clone() for k, _ in r.module.named_parameters()]
         return (None, dx, *grads)
@@ -76,8 +89,10 @@ class _Runner:
         v = self.a_out.act.v
         self.y = torch.empty(N, self.a_out.C, v.H, v.W, dtype=F32, device=self.state.device)
         self.dx = torch.empty(N, C, H, W, dtype=F32, device=self.state.device)
+        self.serial = 0           # forward calls so far
 
     def forward(self, x):
+        self.serial += 1
         ops.nchw_to_nhwc(x.contiguous().to(F32), self.a_in.v)
         self.ctx.begin_forward()
         self.plan.forward()
@@ -411,11 +426,14 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, module, x, *params):
         ctx.module, ctx.key = module, (tuple(x.shape), module.training)
         ctx.need_dx = x.requires_grad
-        return module._net_forward(x)
+        y = module._net_forward(x)
+        ctx.serial = module._plans()[ctx.key].serial
+        return y
 
     @staticmethod
     def backward(ctx, dy):
         m = ctx.module
+        _check_serial(m._plans()[ctx.key], ctx.serial, type(m).__name__)
         dx = m._net_backward(ctx.key, dy.contiguous().to(F32), ctx.need_dx)
         st = m._state
         return (None, dx, *[st.g[k].clone() for k, _ in m.named_parameters()])
@@ -486,6 +504,7 @@ class RIGAN(_PlanModule):
                 raise ValueError("RIGAN expects one-channel images")
             G = plans[key] = engine.Generator(st, N, H, W, grads=True, training=self.training, device=x.device)
         G.x_keep = x.contiguous().to(F32)
+        G.serial = getattr(G, "serial", 0) + 1
         return G.forward(G.x_keep).clone()
 
     def _net_backward(self, key, dy, need_dx):
@@ -535,6 +554,7 @@ class ImageDiscriminator(_PlanModule):
             D = plans[key] = engine.Discriminator(st, N, H, W, grads=True, training=self.training, device=x.device)
             D.dimg = torch.zeros(N, 1, H, W, dtype=F32, device=x.device)
         D.x_keep = x.contiguous().to(F32)
+        D.serial = getattr(D, "serial", 0) + 1
         D.forward(D.x_keep)
         return D.output_nchw()
 

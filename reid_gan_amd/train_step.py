@@ -53,7 +53,7 @@ class TrainStep:
                  batch: int, H: int, W: int, lr: float = 1e-4, weights=(0.3, 0.5, 0.2), device="cuda",
                  use_graph: bool = True, process_group=None):
         ops.require_gpu()
-        self.B, self.H, self.W, self.lr = batch, H, W, lr
+        self.B, self.H, self.W, self._lr = batch, H, W, float(lr)
         self.wv, self.ws, self.wg = weights
         self.device = device
         self.pg = process_group
@@ -70,14 +70,15 @@ class TrainStep:
         if process_group is not None:
             from .dp import Exchanger
             self.xch = Exchanger(process_group)
+        # The discriminator reads cat([target, prediction]) (train.py:158): the target batch and the generator's
+        # output ARE the two halves of that buffer, so nothing is copied to build it.
+        self.d_in = torch.zeros(2 * B, 1, H, W, dtype=F32, device=device)
         self.G = Generator(self.gs, B, H, W, grads=True, training=True, device=device,
-                           grad_buckets=process_group is not None)
+                           grad_buckets=process_group is not None, out=self.d_in[B:])
         self.D = Discriminator(self.ds, 2 * B, H, W, grads=True, training=True, device=device)
         self.V = Vgg(vgg, B, H, W, grads=True, device=device)
         self.x = torch.zeros(B, 1, H, W, dtype=F32, device=device)
-        self.y = torch.zeros(B, 1, H, W, dtype=F32, device=device)
-        self.d_in = torch.zeros(2 * B, 1, H, W, dtype=F32, device=device)
-        self.v_in = torch.zeros(2 * B, 1, H, W, dtype=F32, device=device)
+        self.y = self.d_in[:B]
         self.dpred = torch.zeros(B, 1, H, W, dtype=F32, device=device)
         self.sc = torch.zeros(16, dtype=F32, device=device)
         self.ssim_sums = torch.zeros(B, 4, dtype=F32, device=device)
@@ -94,6 +95,20 @@ class TrainStep:
         self.steps_done = 0
         self.segment = -1
         self._inflight = {}
+
+    @property
+    def lr(self) -> float:
+        """Generator learning rate (the discriminator steps at four times it: train.py:104-105).  The rate is an
+        argument of the captured Adam launches, so assigning a different value drops the captured graphs and the
+        next step() captures again."""
+        return self._lr
+
+    @lr.setter
+    def lr(self, value: float):
+        value = float(value)
+        if value != self._lr:
+            self._lr = value
+            self.graphs = None
 
     @property
     def exchange(self):
@@ -152,8 +167,7 @@ class TrainStep:
         ops.dot(out.v.images(0, B), None, 1.0 / n, sc[SC_MEAN_POS:])
         ops.dot(out.v.images(B, 2 * B), None, 1.0 / n, sc[SC_MEAN_NEG:])
         yield [("sync", sc[SC_MEAN_POS:SC_MEAN_NEG + 1])]    # the hinge acts on the GLOBAL batch means
-        ops.dloss_scalars(sc, n)
-        sc[SC_DLOSS2 if last else SC_DLOSS1].copy_(sc[SC_DLOSS])
+        ops.dloss_scalars(sc, n, keep=sc[SC_DLOSS2 if last else SC_DLOSS1:])
         if last:       # the generator's gradient goes through D as it is now; D's own backward reuses the buffers after
             self._g_loss_backward(n)
         # D's own backward (large kernels) on a side stream beside the generator backward (small, latency-bound
@@ -190,12 +204,11 @@ class TrainStep:
         self.dpred.zero_()
         sc[SC_VGG:SC_SSIM + 1].zero_()
         # perceptual term (loss.py:179-189); the target half of the features was started in _body()
-        self.v_in[:B].copy_(pred)
         if self._vgg_side is not None:
             self._join(self._vgg_side)
             self._vgg_side = None
         self.V.ctx.zero_backward()
-        self.V.forward_pred_fused(self.v_in, self.wv)      # the MSE against the target taps rides in the tap layers
+        self.V.forward_pred_fused(pred, self.wv)      # the MSE against the target taps rides in the tap layers
         self.V.loss_from_rows(sc[SC_VGG:])
         self.V.backward(self.dpred)
         # DSSIM term on raw HU (loss.py:191): ssim(target, pred), gradient to pred
@@ -214,8 +227,7 @@ class TrainStep:
         B = self.B
         self._vgg_side = self._fork(N_LANES, self.overlap_vgg)      # target features beside the generator forward
         with torch.cuda.stream(self._vgg_side):
-            self.v_in[B:].copy_(self.y)
-            self.V.forward(self.v_in, B, 2 * B)
+            self.V.forward(self.y, B, 2 * B, src0=0)
         # The first discriminator iteration's weight preparation (spectral norms, packing) and its forward pass on
         # the TARGET images need nothing the generator computes: they run beside the generator forward too, whose
         # small dependent kernels leave most of the chip idle.
@@ -223,16 +235,13 @@ class TrainStep:
         if self.overlap_dreal and self.D.splittable:
             self._d_side = self._fork(N_LANES + 1)
             with torch.cuda.stream(self._d_side):
-                self.d_in[:B].copy_(self.y)
                 self.D.prepare()
                 self.D.forward_images(self.d_in, 0, B)
         pred = self.G.forward(self.x)
         if self.segmented:           # a side stream may not stay open across a collective (graph segment boundary)
             self._join(self._vgg_side)
             self._vgg_side = None
-        if self._d_side is None:
-            self.d_in[:B].copy_(self.y)
-        self.d_in[B:].copy_(pred)
+        assert pred.data_ptr() == self.d_in[B:].data_ptr()
         yield from self._d_iteration(last=False)
         yield from self._d_iteration(last=True)
         self.gs.adam(self.lr)

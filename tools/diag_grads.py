@@ -38,14 +38,14 @@ ts = TrainStep(gsd, dsd, vgg, 4, 64, 64, use_graph=False)
 ts.x.copy_(x.cuda()); ts.y.copy_(y.cuda())
 B = 4
 pred = ts.G.forward(ts.x)
-ts.d_in[:B].copy_(ts.y); ts.d_in[B:].copy_(pred)
+assert pred.data_ptr() == ts.d_in[B:].data_ptr()      # y and pred are the two halves of d_in
 ts._d_iteration(last=False)
 # second iteration by hand up to the G loss
 out = ts.D.forward(ts.d_in)
 n = out.v.npix // 2 * out.v.C
 ts.dpred.zero_(); ts.sc.zero_()
-ts.v_in[:B].copy_(pred); ts.v_in[B:].copy_(ts.y)
-ts.V.forward(ts.v_in); ts.V.ctx.zero_backward(); ts.V.loss_and_seed(ts.sc[5:], 0.3); ts.V.backward(ts.dpred)
+v_in = torch.cat([pred, ts.y])
+ts.V.forward(v_in); ts.V.ctx.zero_backward(); ts.V.loss_and_seed(ts.sc[5:], 0.3); ts.V.backward(ts.dpred)
 d_vgg = ts.dpred.clone()
 ts.ssim_sums.zero_()
 ops.ssim_fwd(pred, None, ts.y, 1e-4, 9e-4, ts.ssim_sums, gmap=ts.gmap)
