@@ -175,17 +175,23 @@ int ried_bn_apply_images(const void* x, long long ldx, void* y, long long ldy, l
                          ried_stream_t stream);
 /* dx = d(loss)/d(conv output) from dy = d(loss)/d(bn+relu output); scratch: fp32
  * [ried_bn_backward_scratch_floats(C)] (need not be zeroed); dgamma/dbeta may be NULL; counter: NULL, or one
- * zero-initialised unsigned per layer (left at zero) - the last block of the reduction then finishes the sums. */
+ * zero-initialised unsigned per layer (left at zero) - the last block of the reduction then finishes the sums.
+ * folded: NULL, or ZEROED fp32 [ried_bn_backward_folded_floats(C)] owned by the layer (left non-zero): the
+ * reduction's blocks add into a few rows of it with float atomics and the apply pass adds those up itself - two
+ * launches instead of three, sums that depend on the order the blocks finish in; scratch and counter are unused. */
 int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
                      long long npix, int C, const float* save, const float* gamma, const float* beta, int relu,
-                     float* scratch, float* dgamma, float* dbeta, int accumulate, unsigned* counter,
+                     float* scratch, float* dgamma, float* dbeta, int accumulate, unsigned* counter, float* folded,
                      ried_stream_t stream);
 long long ried_bn_backward_scratch_floats(int C);
+long long ried_bn_backward_folded_floats(int C);
 /* Job-table form: ried_bn_backward for njobs layers that share the pixel count (the sibling 1x1 layers of an
  * Inception block, src/rinet.py:99-103,225-233) in three launches in all.  jobs: device table, 16 64-bit words per
- * job: dy, lddy, x, ldx, dx, lddx, C, save, gamma, beta, act, scratch, dgamma, dbeta, accumulate, 0 (meanings as the
- * arguments of ried_bn_backward; every job its own scratch).  maxC: the largest C among the jobs. */
-int ried_bn_backward_jobs(const long long* jobs, int njobs, long long npix, int maxC, ried_stream_t stream);
+ * job: dy, lddy, x, ldx, dx, lddx, C, save, gamma, beta, act, scratch, dgamma, dbeta, accumulate, folded (meanings
+ * as the arguments of ried_bn_backward; every job its own scratch or folded rows).  maxC: the largest C among the
+ * jobs; all_folded: non-zero when every job carries folded rows (two launches in all). */
+int ried_bn_backward_jobs(const long long* jobs, int njobs, long long npix, int maxC, int all_folded,
+                          ried_stream_t stream);
 
 /* ---- pooling / upsampling ------------------------------------------------------------------------------------- */
 /* mode 0: MaxPool2d(3,2,1) (src/rinet.py:260,355); 1: MaxPool2d(2,2) (VGG16); 2: avg_pool2d(3,1,1) (:235,330,428) */

@@ -490,12 +490,16 @@ extern "C" int ried_bn_apply_images(const void* x, long long ldx, void* y, long 
   return RIED_OK;
 }
 
+// Rows of the folded form of the backward sums: the reduction's blocks add their partial sums into row
+// (block % BN_BWD_FOLD_ROWS) of a zeroed [BN_BWD_FOLD_ROWS][2][C] buffer with float atomics and the apply pass adds
+// the rows up itself, so no launch stands between the two (the sums then depend on the order the blocks finish in).
+#define BN_BWD_FOLD_ROWS 8
 // backward pass 1: per-block partial sums[0][c] = sum g, sums[1][c] = sum g*xhat, g = dy * [bn(x) > 0]
 __device__ __forceinline__ void bn_bwd_reduce_body(
     const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx, long long npix, int C,
     const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
     float* __restrict__ sums, unsigned* counter, float* __restrict__ fin, float* dgamma, float* dbeta,
-    int accumulate) {
+    int accumulate, float* __restrict__ folded) {
   __shared__ float red[EW_THREADS][17];           // per-thread partials, padded against bank conflicts
   __shared__ int last_flag;
   ChanWalk w(C);
@@ -528,13 +532,15 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
   __syncthreads();
   // channel j of statistic k: sum over the block's pixel lanes of the thread partials
   const int CC = C >> 3, PPB = EW_THREADS / CC;
-  float* row = sums + (long long)blockIdx.x * 2 * C;
+  float* row = folded ? folded + (long long)(blockIdx.x % BN_BWD_FOLD_ROWS) * 2 * C
+                      : sums + (long long)blockIdx.x * 2 * C;
   for (int j = threadIdx.x; j < 2 * C; j += EW_THREADS) {
     int k = j >= C, ch = j - k * C;
     int t0 = ch >> 3, q = (ch & 7) + 8 * k;
     float acc = 0.f;
     for (int pl = 0; pl < PPB; ++pl) acc += red[pl * CC + t0][q];
-    if (counter) ried_publish(&row[j], acc);      // read by the last block of this launch: write-through
+    if (folded) __hip_atomic_fetch_add(&row[j], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else if (counter) ried_publish(&row[j], acc);      // read by the last block of this launch: write-through
     else row[j] = acc;
   }
   // the last block to arrive reduces the rows (instead of a separate, dependent launch)
@@ -546,15 +552,17 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_kernel(
     const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx, long long npix, int C,
     const float* __restrict__ save, const float* __restrict__ gamma, const float* __restrict__ beta, int relu,
     float* __restrict__ sums, unsigned* counter, float* __restrict__ fin, float* dgamma, float* dbeta,
-    int accumulate) {
-  bn_bwd_reduce_body(dy, lddy, x, ldx, npix, C, save, gamma, beta, relu, sums, counter, fin, dgamma, dbeta, accumulate);
+    int accumulate, float* __restrict__ folded) {
+  bn_bwd_reduce_body(dy, lddy, x, ldx, npix, C, save, gamma, beta, relu, sums, counter, fin, dgamma, dbeta, accumulate,
+                     folded);
 }
 
 // backward pass 2: dx = gamma*invstd*(g - s1/n - xhat*s2/n)
 __device__ __forceinline__ void bn_bwd_apply_body(
     const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx,
     bf16_t* __restrict__ dx, long long lddx, long long npix, int C, const float* __restrict__ save,
-    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, const float* __restrict__ sums) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, const float* __restrict__ sums,
+    int fold_rows, float* dgamma, float* dbeta, int accumulate) {
   ChanWalk w(C);
   if (!w.active) return;
   const int c = w.c;
@@ -564,8 +572,23 @@ __device__ __forceinline__ void bn_bwd_apply_body(
   for (int q = 0; q < 8; ++q) {
     mean[q] = save[c + q]; istd[q] = save[C + c + q];
     a[q] = gamma[c + q] * istd[q]; b[q] = beta[c + q];
-    m1[q] = sums[c + q] * invn; m2[q] = sums[C + c + q] * invn;
+    m1[q] = sums[c + q]; m2[q] = sums[C + c + q];
   }
+  for (int r = 1; r < fold_rows; ++r) {           // the folded form: every thread adds the rows up for its channels
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      m1[q] += sums[(long long)r * 2 * C + c + q]; m2[q] += sums[(long long)r * 2 * C + C + c + q];
+    }
+  }
+  if (fold_rows && dgamma && w.p == 0) {          // ... and the first pixel's threads write the parameter gradients
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      dbeta[c + q] = accumulate ? dbeta[c + q] + m1[q] : m1[q];
+      dgamma[c + q] = accumulate ? dgamma[c + q] + m2[q] : m2[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { m1[q] *= invn; m2[q] *= invn; }
 #pragma unroll 2
   for (long long p = w.p; p < npix; p += w.step) {
     float g[8], xv[8];
@@ -584,8 +607,10 @@ __device__ __forceinline__ void bn_bwd_apply_body(
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_kernel(
     const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx,
     bf16_t* __restrict__ dx, long long lddx, long long npix, int C, const float* __restrict__ save,
-    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, const float* __restrict__ sums) {
-  bn_bwd_apply_body(dy, lddy, x, ldx, dx, lddx, npix, C, save, gamma, beta, relu, sums);
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, const float* __restrict__ sums,
+    int fold_rows, float* dgamma, float* dbeta, int accumulate) {
+  bn_bwd_apply_body(dy, lddy, x, ldx, dx, lddx, npix, C, save, gamma, beta, relu, sums, fold_rows, dgamma, dbeta,
+                    accumulate);
 }
 
 // partial rows [nrows][2][C] -> final sums [2][C] (read by the apply pass) and the parameter gradients
@@ -614,20 +639,21 @@ __global__ __launch_bounds__(ROWRED_THREADS) void bn_bwd_finish_kernel(const flo
 #define BN_BWD_MAX_ROWS 1024
 // Job-table form: the BatchNorm backward of several layers that share the pixel count (the sibling 1x1 layers of an
 // Inception block) in three launches instead of three per layer.  A job is 16 64-bit words:
-// dy, lddy, x, ldx, dx, lddx, C, save, gamma, beta, act, scratch, dgamma, dbeta, accumulate, 0  (as ried_bn_backward).
+// dy, lddy, x, ldx, dx, lddx, C, save, gamma, beta, act, scratch, dgamma, dbeta, accumulate, folded
+// (as ried_bn_backward; folded = 0, or the job's zeroed rows of the folded form, and then scratch may be 0).
 #define BN_JOB_WORDS 16
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_jobs_kernel(const long long* __restrict__ jobs,
                                                                         long long npix) {
   const long long* J = jobs + (long long)blockIdx.y * BN_JOB_WORDS;
   bn_bwd_reduce_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], npix, (int)J[6], (const float*)J[7],
                      (const float*)J[8], (const float*)J[9], (int)J[10], (float*)J[11], nullptr, nullptr, nullptr,
-                     nullptr, 0);
+                     nullptr, 0, (float*)J[15]);
 }
 __global__ __launch_bounds__(ROWRED_THREADS) void bn_bwd_finish_jobs_kernel(const long long* __restrict__ jobs,
                                                                             int nrows) {
   const long long* J = jobs + (long long)blockIdx.y * BN_JOB_WORDS;
   const int C = (int)J[6];
-  if ((int)blockIdx.x * 32 >= C) return;
+  if ((int)blockIdx.x * 32 >= C || J[15]) return;
   float* scratch = (float*)J[11];
   float* dg = (J[12] && J[13]) ? (float*)J[12] : nullptr;
   bn_bwd_finish_body(scratch, nrows, C, scratch + (long long)BN_BWD_MAX_ROWS * 2 * C, dg, (float*)J[13], (int)J[14]);
@@ -636,18 +662,27 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_jobs_kernel(const lon
                                                                        long long npix) {
   const long long* J = jobs + (long long)blockIdx.y * BN_JOB_WORDS;
   const int C = (int)J[6];
-  bn_bwd_apply_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], (bf16_t*)J[4], J[5], npix, C,
-                    (const float*)J[7], (const float*)J[8], (const float*)J[9], (int)J[10],
-                    (const float*)J[11] + (long long)BN_BWD_MAX_ROWS * 2 * C);
+  float* dg = (J[12] && J[13]) ? (float*)J[12] : nullptr;
+  if (J[15])
+    bn_bwd_apply_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], (bf16_t*)J[4], J[5], npix, C,
+                      (const float*)J[7], (const float*)J[8], (const float*)J[9], (int)J[10], (const float*)J[15],
+                      BN_BWD_FOLD_ROWS, dg, (float*)J[13], (int)J[14]);
+  else
+    bn_bwd_apply_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], (bf16_t*)J[4], J[5], npix, C,
+                      (const float*)J[7], (const float*)J[8], (const float*)J[9], (int)J[10],
+                      (const float*)J[11] + (long long)BN_BWD_MAX_ROWS * 2 * C, 0, nullptr, nullptr, 0);
 }
-// jobs: device table of njobs records; maxC: the largest channel count among them (sizes the grids)
-extern "C" int ried_bn_backward_jobs(const long long* jobs, int njobs, long long npix, int maxC, hipStream_t stream) {
+// jobs: device table of njobs records; maxC: the largest channel count among them (sizes the grids);
+// all_folded: every job carries folded rows, so the launch that finishes the per-block rows is left out
+extern "C" int ried_bn_backward_jobs(const long long* jobs, int njobs, long long npix, int maxC, int all_folded,
+                                     hipStream_t stream) {
   RIED_CHECK_ARG(jobs && njobs > 0 && njobs <= 65535 && npix > 0 && maxC >= 8 && maxC % 8 == 0 && maxC <= 8 * EW_THREADS,
                  "ried_bn_backward_jobs: bad arguments");
   const int grid = chan_grid(npix, maxC, 4, BN_BWD_MAX_ROWS);
   hipLaunchKernelGGL(bn_bwd_reduce_jobs_kernel, dim3(grid, njobs), dim3(EW_THREADS), 0, stream, jobs, npix);
-  hipLaunchKernelGGL(bn_bwd_finish_jobs_kernel, dim3(ceil_div(maxC, 32), njobs), dim3(ROWRED_THREADS), 0, stream, jobs,
-                     grid);
+  if (!all_folded)
+    hipLaunchKernelGGL(bn_bwd_finish_jobs_kernel, dim3(ceil_div(maxC, 32), njobs), dim3(ROWRED_THREADS), 0, stream,
+                       jobs, grid);
   hipLaunchKernelGGL(bn_bwd_apply_jobs_kernel, dim3(chan_grid(npix, maxC, 2, 8192), njobs), dim3(EW_THREADS), 0, stream,
                      jobs, npix);
   RIED_CHECK_LAUNCH("ried_bn_backward_jobs");
@@ -657,31 +692,44 @@ extern "C" int ried_bn_backward_jobs(const long long* jobs, int njobs, long long
 // scratch: fp32 [(BN_BWD_MAX_ROWS + 1) * 2 * C] (need not be zeroed).  dgamma/dbeta may be null.
 // counter: null, or one zero-initialised unsigned (left at zero): the reduction's last block then finishes the
 // sums itself instead of a separate launch.
+// folded: null, or ZEROED fp32 [ried_bn_backward_folded_floats(C)] (left non-zero): the folded form, two launches,
+// scratch and counter unused (scratch may be null).
 extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
                                 long long npix, int C, const float* save, const float* gamma, const float* beta,
                                 int relu, float* scratch, float* dgamma, float* dbeta, int accumulate,
-                                unsigned* counter, hipStream_t stream) {
+                                unsigned* counter, float* folded, hipStream_t stream) {
   CHECK_VIEW("ried_bn_backward", dy, lddy, C);
   CHECK_VIEW("ried_bn_backward", x, ldx, C);
   CHECK_VIEW("ried_bn_backward", dx, lddx, C);
-  RIED_CHECK_ARG(save && gamma && beta && scratch && npix > 0, "ried_bn_backward: bad arguments");
+  RIED_CHECK_ARG(save && gamma && beta && (scratch || folded) && npix > 0, "ried_bn_backward: bad arguments");
   RIED_CHECK_ARG(C <= 8 * EW_THREADS, "ried_bn_backward: C too large");
   int grid = chan_grid(npix, C, 4, BN_BWD_MAX_ROWS);
-  float* fin = scratch + (long long)BN_BWD_MAX_ROWS * 2 * C;
   float* dg = (dgamma && dbeta) ? dgamma : nullptr;
+  if (folded) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)dy, lddy,
+                       (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, (float*)nullptr, (unsigned*)nullptr,
+                       (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, folded);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chan_grid(npix, C, 2, 8192)), dim3(EW_THREADS), 0, stream,
+                       (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (bf16_t*)dx, lddx, npix, C, save, gamma, beta,
+                       relu, (const float*)folded, BN_BWD_FOLD_ROWS, dg, dbeta, accumulate);
+    RIED_CHECK_LAUNCH("ried_bn_backward");
+    return RIED_OK;
+  }
+  float* fin = scratch + (long long)BN_BWD_MAX_ROWS * 2 * C;
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)dy, lddy,
                      (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, scratch, counter, fin, dg, dbeta,
-                     accumulate);
+                     accumulate, (float*)nullptr);
   if (!counter)
     hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(ceil_div(C, 32)), dim3(ROWRED_THREADS), 0, stream, scratch, grid,
                        C, fin, dg, dbeta, accumulate);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chan_grid(npix, C, 2, 8192)), dim3(EW_THREADS), 0, stream,
                      (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (bf16_t*)dx, lddx, npix, C, save, gamma, beta,
-                     relu, fin);
+                     relu, (const float*)fin, 0, (float*)nullptr, (float*)nullptr, 0);
   RIED_CHECK_LAUNCH("ried_bn_backward");
   return RIED_OK;
 }
 extern "C" long long ried_bn_backward_scratch_floats(int C) { return (long long)(BN_BWD_MAX_ROWS + 1) * 2 * C; }
+extern "C" long long ried_bn_backward_folded_floats(int C) { return (long long)BN_BWD_FOLD_ROWS * 2 * C; }
 
 // ---------------------------------------------------------------------------
 // BatchNorm forward for small layers in one launch after the conv instead of two.  Blocks own a slice of up to 64

@@ -121,6 +121,7 @@ class Ctx:
         self._f32: List[Tuple[torch.Tensor, int, int]] = []
         self.stats_elems = 0          # fp32 arena of per-tile partial rows (BN sums, bias sums): overwritten
         self.fold_elems = 0           # fp32 arena zeroed at the start of every forward (folded BN sums)
+        self.bfold_elems = 0          # fp32 arena zeroed at the start of every backward (folded BN backward sums)
         self.slab_elems = 0
         self.tmp_elems = 0
         self.f32_elems = 0            # shared fp32 scratch (BN backward partial rows, column sums)
@@ -166,8 +167,11 @@ class Ctx:
 
     def stats(self, owner, attr, n, zeroed=False):
         """fp32 statistics rows for `owner.attr`; zeroed: from the arena that begin_forward() clears (rows the
-        conv epilogues add into)."""
-        if zeroed:
+        conv epilogues add into), or, zeroed="backward", from the one zero_backward() clears."""
+        if zeroed == "backward":
+            self._stats_req.append((owner, attr, ("b", self.bfold_elems)))
+            self.bfold_elems += (n + 3) // 4 * 4
+        elif zeroed:
             self._stats_req.append((owner, attr, -1 - self.fold_elems))
             self.fold_elems += (n + 3) // 4 * 4
         else:
@@ -217,8 +221,12 @@ class Ctx:
                 seen.add(id(g))
         self.stats_arena = torch.zeros(max(self.stats_elems, 4), dtype=F32, device=dev)
         self.fold_arena = torch.zeros(max(self.fold_elems, 4), dtype=F32, device=dev)
+        self.bfold_arena = torch.zeros(max(self.bfold_elems, 4), dtype=F32, device=dev)
         for owner, attr, off in self._stats_req:
-            arena, off = (self.stats_arena, off) if off >= 0 else (self.fold_arena, -1 - off)
+            if isinstance(off, tuple):
+                arena, off = self.bfold_arena, off[1]
+            else:
+                arena, off = (self.stats_arena, off) if off >= 0 else (self.fold_arena, -1 - off)
             setattr(owner, attr, arena[off:off + getattr(owner, attr + "_n")])
         self.slab = torch.empty(max(self.slab_elems, 4), dtype=F32, device=dev)
         for table, j, off in self._wred_slab:
@@ -254,6 +262,8 @@ class Ctx:
     def zero_backward(self):
         if not self.chain:       # a chain plan overwrites every gradient buffer before reading it
             self.grad_arena.zero_()
+        if self.bfold_elems:     # the BatchNorm backward sums the reductions add into
+            self.bfold_arena.zero_()
 
     def sn_sigmas(self):
         """One power iteration (training) and sigma = u^T W v for every spectral-norm layer; must precede
@@ -275,6 +285,8 @@ class Ctx:
 
 
 N_LANES = 4
+# side_stream() numbers beyond the Inception lanes 1..N_LANES-1: whole networks run beside each other
+VGG_LANE, DBWD_LANE, REPLICA_LANE0 = N_LANES, N_LANES + 1, N_LANES + 2
 # Train-mode BatchNorm layers of at most BN_FOLD_MAX_ELEMS elements fold their statistics into a few rows with
 # float atomics in the conv epilogue and skip the finalize launch (about 1 % of the step).  The price: the sums
 # depend on the order in which the conv's blocks finish, so two runs differ in the last bits.  BN_FOLD = False
@@ -496,10 +508,15 @@ class ConvBN:
         self.draw: Optional[View] = None
         if fwd_member:
             grp.join(self)
+        self.bwd_fold = False
         if ctx.grads:
             ctx.need_f32(ops.bn_backward_scratch_floats(cout))
             if bias:
                 ctx.need_f32(ops.colsum_scratch_floats(cout))
+            # small layers: the backward sums are folded with float atomics too (one dependent launch fewer)
+            self.bwd_fold = BN_FOLD and BN_BWD_FOLD and self.raw.npix * cout <= BN_FOLD_MAX_ELEMS
+            if self.bwd_fold:
+                ctx.stats(self, "bfold", ops.bn_backward_folded_floats(cout), zeroed="backward")
             # the gradient w.r.t. the conv output keeps its own buffer, so that the weight gradient can wait for
             # the grouped launch at the end of the backward pass
             if grouped:
@@ -578,7 +595,7 @@ class ConvBN:
             return
         ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
                         ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=self.act,
-                        accumulate=self.shared)
+                        accumulate=self.shared, folded=self.bfold if self.bwd_fold else None)
         if self.bias_key:        # zero up to rounding in train mode, as in torch's autograd
             ops.colsum(draw, st.g[self.bias_key], ctx.f32s[self.lane])
         c.wgrad(draw)
@@ -671,7 +688,8 @@ class InputGradGroup:
         if ctx.grads and ctx.st is not None and len(self.members) >= 2 and not any(m.bias_key for m in self.members):
             for m in self.members:
                 m.bn_bwd_grouped = True
-                m._bn_scratch = torch.empty(ops.bn_backward_scratch_floats(m.core.cout), dtype=F32, device=ctx.device)
+                m._bn_scratch = (None if m.bwd_fold else
+                                 torch.empty(ops.bn_backward_scratch_floats(m.core.cout), dtype=F32, device=ctx.device))
             ctx._late.append(self._make_bn_jobs)        # the gradient views have addresses only after finalize()
         return self
 
@@ -679,7 +697,9 @@ class InputGradGroup:
         st = self.ctx.st
         rows = [ops.bn_backward_job(m.out.g, m.raw, m.draw, m.save, st.p[m.bn + ".weight"], st.p[m.bn + ".bias"],
                                     m._bn_scratch, st.g[m.bn + ".weight"], st.g[m.bn + ".bias"], act=m.act,
-                                    accumulate=m.shared) for m in self.members]
+                                    accumulate=m.shared, folded=m.bfold if m.bwd_fold else None)
+                for m in self.members]
+        self.bn_all_folded = all(m.bwd_fold for m in self.members)
         self.bn_jobs = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
         self.bn_maxc = max(m.core.cout for m in self.members)
         self.npix = self.drawcat.npix
@@ -708,7 +728,7 @@ class InputGradGroup:
         if not self.ctx.grads:
             return
         if self.bn_jobs is not None:
-            ops.bn_backward_jobs(self.bn_jobs, len(self.members), self.npix, self.bn_maxc)
+            ops.bn_backward_jobs(self.bn_jobs, len(self.members), self.npix, self.bn_maxc, self.bn_all_folded)
         ops.conv2d(self.drawcat, self.wcat, self.xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True)
 
 
@@ -716,6 +736,7 @@ SIBLING_GROUPS = not os.environ.get("RIED_NO_SIBLING_GROUPS")      # switch for 
 FUSED_ATTN = not os.environ.get("RIED_NO_FUSED_ATTN")
 PACK_TILES = not os.environ.get("RIED_NO_PACK_TILES")
 FWD_BN_JOBS = not os.environ.get("RIED_NO_FWD_BN_JOBS")
+BN_BWD_FOLD = not os.environ.get("RIED_NO_BN_BWD_FOLD")
 
 
 def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
@@ -1082,6 +1103,8 @@ class Generator:
     # first top-level module of each gradient bucket, in forward (= flat parameter) order; the backward pass
     # completes the buckets last to first
     BUCKET_STARTS = ("conv1", "layer_block_3")
+    # (Measured without data parallelism: launching each bucket's deferred weight gradients on a side stream, beside
+    # the remaining layers' small kernels, makes the step 0.09 ms slower; they stay at the end of the pass.)
 
     def __init__(self, state: State, N: int, H: int, W: int, grads=True, training=True, device="cuda",
                  out: Optional[torch.Tensor] = None, per_image_stats: bool = False, grad_buckets: bool = False):
@@ -1109,10 +1132,11 @@ class Generator:
         body = Seq()
         self.bucket_first = [0]        # index into body.layers of the first layer of buckets 1, 2, ... (bucket 0: conv1)
         bucketed = grads and grad_buckets
+        starts_at = self.BUCKET_STARTS if bucketed else ()
 
-        def bucket(n):
-            if bucketed:
-                ctx.set_bucket(n)
+        def bucket(name):
+            if name in starts_at[1:]:
+                ctx.set_bucket(starts_at.index(name))
                 self.bucket_first.append(len(body.layers))
         c2 = self.cat1.sub(0, 64)
         body.add(ConvBN(ctx, "conv2", 32, 64, 3, 2, 1, self.cat2.sub(0, 32), c2))
@@ -1120,7 +1144,7 @@ class Generator:
         a2 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_b(ctx, "reduce_grid_1", a1, a2, 128, False))
         a3 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_c(ctx, "layer_block_2.0", a2, a3, 256, 64, False))
         a4 = Slot(ctx.act(N, h16, w16, 512)); body.add(inception_d(ctx, "reduce_grid_2", a3, a4, 256, False))
-        bucket(1)
+        bucket("layer_block_3")
         a5 = Slot(ctx.act(N, h16, w16, 1024)); body.add(inception_e(ctx, "layer_block_3.0", a4, a5, 512, True))
         a6 = Slot(ctx.act(N, h8, w8, 512)); body.add(inception_d(ctx, "expand_grid_1", a5, a6, 1024, True))
         a7 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_c(ctx, "layer_block_4.0", a6, a7, 512, 64, True))
@@ -1142,7 +1166,7 @@ class Generator:
         self.x = None
         # [lo, hi) of the flat parameter / gradient buffer per bucket (parameters are laid out in module order)
         starts = [state.offs[min((k for k in state.offs if k.startswith(p + ".")), key=state.offs.get)]
-                  for p in (self.BUCKET_STARTS if bucketed else self.BUCKET_STARTS[:1])]
+                  for p in (starts_at or self.BUCKET_STARTS[:1])]
         assert starts == sorted(starts) and starts[0] == 0
         self.bucket_ranges = list(zip(starts, starts[1:] + [state.flat.numel()]))
 

@@ -310,22 +310,29 @@ def bn_apply_images(x: View, y: View, save, gamma, beta, relu=True, accumulate=F
 
 
 def bn_backward(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma=None, dbeta=None, relu=True,
-                accumulate=False, counter: Optional[torch.Tensor] = None):
+                accumulate=False, counter: Optional[torch.Tensor] = None, folded: Optional[torch.Tensor] = None):
     """scratch: fp32, at least bn_backward_scratch_floats(C) elements.  counter: a zeroed int32 element owned by
-    the layer; with it the reduction's last block finishes the sums (one launch fewer)."""
+    the layer; with it the reduction's last block finishes the sums (one launch fewer).  folded: zeroed fp32
+    [bn_backward_folded_floats(C)] owned by the layer (left non-zero): two launches, atomically folded sums."""
     lib.ried_bn_backward(dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta),
-                         int(relu), _p(scratch), _p(dgamma), _p(dbeta), int(accumulate), _p(counter), _stream())
+                         int(relu), _p(scratch), _p(dgamma), _p(dbeta), int(accumulate), _p(counter), _p(folded),
+                         _stream())
 
 
-def bn_backward_job(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma, dbeta, act=1, accumulate=False):
+def bn_backward_folded_floats(C: int) -> int:
+    return lib.ried_bn_backward_folded_floats(C)
+
+
+def bn_backward_job(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma, dbeta, act=1, accumulate=False,
+                    folded: Optional[torch.Tensor] = None):
     """One 16-word record of the table bn_backward_jobs takes."""
-    return [dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.C, _p(save), _p(gamma), _p(beta), int(act), _p(scratch),
-            _p(dgamma) or 0, _p(dbeta) or 0, int(accumulate), 0]
+    return [dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.C, _p(save), _p(gamma), _p(beta), int(act),
+            _p(scratch) or 0, _p(dgamma) or 0, _p(dbeta) or 0, int(accumulate), _p(folded) or 0]
 
 
-def bn_backward_jobs(table: torch.Tensor, njobs: int, npix: int, maxC: int):
+def bn_backward_jobs(table: torch.Tensor, njobs: int, npix: int, maxC: int, all_folded: bool = False):
     """table: int64 device tensor [njobs][16] of bn_backward_job records (layers sharing the pixel count)."""
-    lib.ried_bn_backward_jobs(_p(table), njobs, npix, maxC, _stream())
+    lib.ried_bn_backward_jobs(_p(table), njobs, npix, maxC, int(all_folded), _stream())
 
 
 def bn_apply_train_job(x: View, y: View, stats_ptr: int, nrows, ldstat, save, rm, rv, nbt, gamma, beta, act=1,

@@ -362,8 +362,10 @@ class _SNRunner:
         self.N = N
         self.y = torch.empty(N, cout, Ho, Wo, dtype=F32, device=dev)
         self.dx = torch.zeros(N, C, H, W, dtype=F32, device=dev)
+        self.serial = 0           # forward calls so far
 
     def forward(self, x):
+        self.serial += 1
         x = x.contiguous().to(F32)
         self.ctx.sn_sigmas()
         self.ctx.begin_forward()

@@ -28,7 +28,7 @@ from typing import Dict, Optional
 import torch
 
 from . import ops
-from .engine import Discriminator, Generator, State, Vgg, side_stream, N_LANES
+from .engine import Discriminator, Generator, State, Vgg, side_stream, N_LANES, VGG_LANE, DBWD_LANE, REPLICA_LANE0
 
 F32 = torch.float32
 
@@ -174,7 +174,7 @@ class TrainStep:
         # kernels; its Inception branches fork from the stream it runs on).  Data parallel: the side stream rejoins
         # when the generator's first gradient bucket is complete, and both exchanges start there, in flight during
         # the second half of the generator backward.
-        side = self._fork(N_LANES + 1, last and self.overlap_gbwd)
+        side = self._fork(DBWD_LANE, last and self.overlap_gbwd)
         with torch.cuda.stream(side):
             D.ctx.zero_backward()
             self.ds.zero_grad()
@@ -225,7 +225,7 @@ class TrainStep:
 
     def _body(self):
         B = self.B
-        self._vgg_side = self._fork(N_LANES, self.overlap_vgg)      # target features beside the generator forward
+        self._vgg_side = self._fork(VGG_LANE, self.overlap_vgg)      # target features beside the generator forward
         with torch.cuda.stream(self._vgg_side):
             self.V.forward(self.y, B, 2 * B, src0=0)
         # The first discriminator iteration's weight preparation (spectral norms, packing) and its forward pass on
@@ -233,7 +233,7 @@ class TrainStep:
         # small dependent kernels leave most of the chip idle.
         self._d_side = None
         if self.overlap_dreal and self.D.splittable:
-            self._d_side = self._fork(N_LANES + 1)
+            self._d_side = self._fork(DBWD_LANE)
             with torch.cuda.stream(self._d_side):
                 self.D.prepare()
                 self.D.forward_images(self.d_in, 0, B)
@@ -413,13 +413,13 @@ class SliceInference(InferenceEngine):
         saved, eng.PAR_BRANCHES = eng.PAR_BRANCHES, False      # the plans, not their Inception branches, run in parallel
         try:
             for lane in range(self.lanes):
-                s = side_stream(N_LANES + 2 + lane)
+                s = side_stream(REPLICA_LANE0 + lane)
                 s.wait_stream(main)
                 with torch.cuda.stream(s):
                     for i in range(lane, self.B, self.lanes):
                         self.plans[i].forward(self.x[i:i + 1])
             for lane in range(self.lanes):
-                main.wait_stream(side_stream(N_LANES + 2 + lane))
+                main.wait_stream(side_stream(REPLICA_LANE0 + lane))
         finally:
             eng.PAR_BRANCHES = saved
         dr = self.hi - self.lo

@@ -61,3 +61,29 @@ def test_train_step_checkpoint_round_trip(tmp_path):
     for k in la:
         assert abs(la[k] - lb[k]) <= 5e-3 * abs(la[k]) + 1e-6, (k, la[k], lb[k])
     assert torch.allclose(a.gs.flat, b.gs.flat, rtol=0, atol=2.5e-4)       # one Adam step apart at most: lr = 1e-4
+
+
+def test_restored_learning_rate_is_applied_and_recaptures(tmp_path):
+    """A checkpoint saved at another learning rate: restore() applies the optimizer's stored rate, the captured
+    graphs (which hold the rate as a launch argument) are dropped, and the next step moves the parameters by the
+    new rate: as far as the twin that has been stepping at that rate all along."""
+    B, H = 2, 64
+    gsd, dsd, vgg = synth_state(_spec("G"), 101), synth_state(_spec("D"), 202), synth_vgg()
+    x, y = synth_batch(B, H, seed=3)
+    a = TrainStep(gsd, dsd, vgg, B, H, H, lr=4e-4, use_graph=False)
+    a.step(x.to(DEV), y.to(DEV))
+    path = str(tmp_path / "ckpt.pth.tar")
+    C.save_checkpoint(path, a, epoch=0, total_iters=1)
+    b = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+    b.step(x.to(DEV), y.to(DEV))
+    assert b.graphs is not None and b.lr == 1e-4
+    C.restore(b, C.load_checkpoint(path))
+    assert b.lr == 4e-4 and b.graphs is None
+    assert torch.equal(a.gs.flat, b.gs.flat)
+    before = b.gs.flat.clone()
+    a.step(); b.step()
+    torch.cuda.synchronize()
+    assert b.graphs is not None
+    move_a = (a.gs.flat - before).abs().median().item()
+    move_b = (b.gs.flat - before).abs().median().item()
+    assert 0.8 < move_b / move_a < 1.25, (move_a, move_b)      # a step at the old rate would give 0.25

@@ -380,7 +380,9 @@ def test_train_step_at_the_benchmark_batch():
         c_ref, r_ref = cos_ratio(f32["g_grads"][k], g)
         rows.append((c_eng, c_ref, r_eng, r_ref, k))
         closer += c_eng >= c_ref
-        if c_eng < min(0.95, c_ref - 0.1) or abs(r_eng - 1) > max(0.3, 2.0 * abs(r_ref - 1)):
+        # norm: within 30 % (or twice the fp32 run's own deviation); a tensor on which the two oracle runs only agree
+        # to cosine c is noise to that degree, and noise adds to the norm: (1 - c) more is allowed
+        if c_eng < min(0.95, c_ref - 0.1) or abs(r_eng - 1) > max(0.3, 2.0 * abs(r_ref - 1)) + (1 - min(c_ref, 1.0)):
             bad.append((k, round(c_eng, 4), round(c_ref, 4), round(r_eng, 3), round(r_ref, 3)))
     rows.sort()
     print("worst generator gradients (cos engine-emu, cos fp32-emu, norm ratios):", rows[:8])

@@ -545,6 +545,17 @@ def test_bn_forward_backward():
         torch.cuda.synchronize()
         assert counter.item() == 0
         assert torch.equal(dx2.torch(), dxv.torch()) and torch.equal(dg2, dg) and torch.equal(db2, db)
+    # the folded form: sums added into a few zeroed rows with float atomics, no finishing launch, no scratch;
+    # parameter gradients accumulate when asked to
+    folded = torch.zeros(ops.bn_backward_folded_floats(C), device=DEV)
+    dx3 = ops.new_view(N, H, H, C)
+    dg3, db3 = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+    ops.bn_backward(to_view(dy), xv, dx3, save, gamma.to(DEV), beta.to(DEV), None, dg3, db3, accumulate=True,
+                    folded=folded)
+    close(from_view(dx3), xr.grad, what="dx (folded)")
+    close(dg3.cpu() - 1, g2.grad, 5e-3, "dgamma (folded)")
+    close(db3.cpu() - 1, b2.grad, 5e-3, "dbeta (folded)")
+    assert (dx3.torch().float() - dxv.torch().float()).abs().max() <= 2e-2 * dxv.torch().float().abs().max()
 
 
 @pytest.mark.parametrize("C,cin,H", [(48, 32, 8), (160, 64, 8), (16, 64, 16), (1024, 64, 4)])

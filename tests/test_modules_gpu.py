@@ -233,3 +233,31 @@ def test_reference_training_loop_shape():
     assert np.isfinite(gloss.item())
     sd = Gnet.state_dict()
     assert set(sd) == set(gsd) and not torch.equal(sd["out_conv.weight"].cpu(), gsd["out_conv.weight"])
+
+
+def test_backward_of_a_superseded_forward_is_refused():
+    """A module's plan holds the activations of its last forward per input shape: the backward of an earlier
+    forward of that shape raises instead of using the later call's activations."""
+    torch.manual_seed(0)
+    m = _load(rinet.BasicConv2d(16, 16, kernel_size=3, padding=1), 5).to(DEV)
+    x1 = torch.randn(2, 16, 8, 8, device=DEV, requires_grad=True)
+    x2 = torch.randn(2, 16, 8, 8, device=DEV, requires_grad=True)
+    y1 = m(x1)
+    y2 = m(x2)
+    with pytest.raises(RuntimeError, match="forward call"):
+        y1.sum().backward()
+    y2.sum().backward()                              # the latest forward is fine
+    assert x2.grad is not None and torch.isfinite(x2.grad).all()
+    d = _load(rinet.ImageDiscriminator(), 202).to(DEV)
+    a = torch.randn(2, 1, 64, 64, device=DEV)
+    o1 = d(a)
+    o2 = d(a + 1)
+    with pytest.raises(RuntimeError, match="forward call"):
+        o1.mean().backward()
+    o2.mean().backward()
+
+
+def test_psnr_of_identical_images_is_inf():
+    """measure.py:29-32: log10(range^2 / 0) is inf in the reference, not an exception."""
+    a = torch.rand(1, 1, 64, 64, device=DEV)
+    assert measure.compute_PSNR(a, a.clone(), 1.0) == float("inf")
