@@ -192,6 +192,7 @@ class _LegacyNet(_PlanModule):
                 raise ValueError(f"{type(self).__name__} expects one-channel images")
             P = plans[key] = self._plan_cls(st, N, H, W, grads=True, training=self.training, device=x.device)
         P.x_keep = x.contiguous().to(F32)
+        P.serial = getattr(P, "serial", 0) + 1        # (rinet._NetFn refuses the backward of a superseded forward)
         return P.forward(P.x_keep).clone()
 
     def forward(self, input):

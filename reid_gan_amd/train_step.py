@@ -25,6 +25,8 @@ from __future__ import annotations
 
 from typing import Dict, Optional
 
+import os
+
 import torch
 
 from . import ops
@@ -36,15 +38,18 @@ F32 = torch.float32
 SC_MEAN_POS, SC_MEAN_NEG, SC_DLOSS, SC_CPOS, SC_CNEG, SC_VGG, SC_SSIM, SC_DSSIM, SC_GEN, SC_GLOSS = range(10)
 SC_DLOSS1, SC_DLOSS2 = 10, 11
 
-# Captured graphs are kept until the process ends.  On this ROCm release (7.2), destroying a graph captured across
-# many streams while a graph captured after it is still alive makes the first replay of the next capture crash in
-# the runtime (host segmentation fault in hipGraphLaunch); a graph that is never destroyed costs a few host
-# objects (nothing is allocated during these captures, so the graphs' private memory pools are empty).
+# Captured graphs are destroyed with the object that owns them.  An earlier state of this package crashed in the
+# runtime (host segmentation fault in hipGraphLaunch) at the first replay of a capture made after a many-stream graph
+# had been destroyed, and therefore kept every graph until the process ended.  The sequence no longer reproduces:
+# tools/graph_destroy_repro.py (capture A, capture B, destroy A, replay B, capture C, replay C; torch-only graphs
+# with and without a shared pool, and the real step) and the whole GPU test suite run clean with graphs freed.
+# RIED_RETAIN_GRAPHS=1 brings the old behaviour back (a leak of a few host objects per capture).
 _RETAINED_GRAPHS = []
 
 
 def _retain(graph):
-    _RETAINED_GRAPHS.append(graph)
+    if os.environ.get("RIED_RETAIN_GRAPHS"):
+        _RETAINED_GRAPHS.append(graph)
     return graph
 
 
