@@ -99,6 +99,18 @@ int ried_conv2d_wgrad_make_job(void* job_host, const void* g, long long ldg, int
                                const void* p, long long ldp, int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw,
                                int ph, int pw, float* slab, int splitk, int* tile, int* nblocks);
 int ried_conv2d_wgrad_jobs(const void* jobs, const int* map, int nblocks, int bm, int bn, ried_stream_t stream);
+/* Job-table form of ried_conv2d: convolutions that do not depend on each other - the same-depth BasicConv2d layers
+ * of an Inception block's branches (src/rinet.py:237-252, 325-347, 419-445), forward or data gradient - as ONE
+ * launch of the general kernel with 64 x 64 tiles, instead of one launch per branch.  ried_conv2d_make_job fills a
+ * HOST record of ried_conv2d_job_bytes() bytes (arguments as ried_conv2d; statistics only in the folded form,
+ * stats_post = 2) and reports the job's block count; records are copied to the device back to back and launched
+ * with ried_conv2d_jobs, map[2b], map[2b+1] = (job, block of that job) for b < nblocks. */
+int ried_conv2d_job_bytes(void);
+int ried_conv2d_make_job(void* job_host, const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg,
+                         int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                         int transposed, const float* bias, int act, float* stats, int accumulate, int stats_post,
+                         int* nblocks);
+int ried_conv2d_jobs(const void* jobs, const int* map, int nblocks, ried_stream_t stream);
 int ried_conv2d_wgrad_tiles(int Cg, int Cp); /* blocks per (tap, split) of ried_conv2d_wgrad: for choosing splitk */
 /* out[tap*st + p*sp + g*sg] (+)= scale * sum over splits: scatters into the (Cout,Cin,kh,kw) or (Cin,Cout,kh,kw)
  * fp32 master gradient. */

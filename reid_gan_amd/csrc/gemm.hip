@@ -773,14 +773,14 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned byt
 }
 
 // NT threads: 256 (2 x 2 waves) or 512 (2 x 4 waves: twice the pixels per block for the same weight traffic).
-template <int BM, int BN, int NST, int NT = 256>
-__global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
+// (bx, by) of (nbx, nby): the block's place in the problem's own grid (the launch grid, or a job's share of one)
+template <int BM, int BN, int NST, int NT>
+__device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int by, int nbx, int nby, char* smem) {
   constexpr int WN = NT / 128;                        // waves along the pixel axis
   constexpr int RPP = NT / 8;                         // rows per DMA pass (8 lanes = one 128-byte row)
   constexpr int TM = BM / 32, TN = BN / (16 * WN);
   constexpr int NLA = BM / RPP, NLB = BN / RPP;       // 16-byte DMA loads per lane per stage
   constexpr int STAGE = (BM + BN) * 128;              // bytes per stage: A image then B image
-  __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -788,9 +788,9 @@ __global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
 
   // XCD-aware order: consecutive hardware block ids go round-robin over the 8 XCDs; give each XCD a
   // contiguous run of logical tiles so that the blocks sharing a pixel tile hit one L2.
-  int bid = blockIdx.x;
+  int bid = bx;
   {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int nwg = nbx, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tm = bid % P.tiles_m, tn = bid / P.tiles_m;
@@ -799,8 +799,8 @@ __global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
   const GemmOperand& X = P.B;
   int pa = 0, pb = 0, r0 = 0, s0 = 0, ti_n = X.kh, tj_n = X.kw;
   const int dir = X.transposed ? -1 : 1;
-  if (X.transposed) {                     // blockIdx.y = output phase; only its non-zero taps
-    pa = blockIdx.y / X.sw; pb = blockIdx.y % X.sw;
+  if (X.transposed) {                     // by = output phase; only its non-zero taps
+    pa = by / X.sw; pb = by % X.sw;
     r0 = (pa + X.ph) % X.sh; s0 = (pb + X.pw) % X.sw;
     ti_n = (X.kh - r0 + X.sh - 1) / X.sh; tj_n = (X.kw - s0 + X.sw - 1) / X.sw;
   }
@@ -910,11 +910,29 @@ __global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may outlive the block or race the epilogue
   __builtin_amdgcn_s_barrier();
   if (P.E.staged)
-    gemm_epilogue_staged<BM, BN, WN, NST * STAGE>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, gridDim.x / P.tiles_m,
-                                                  blockIdx.y, smem);
+    gemm_epilogue_staged<BM, BN, WN, NST * STAGE>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, nbx / P.tiles_m, by,
+                                                  smem);
   else
-    gemm_epilogue<BM, BN, false, WN>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, 0, gridDim.x / P.tiles_m,
-                                     blockIdx.y, 0, gridDim.x * gridDim.y, smem);
+    gemm_epilogue<BM, BN, false, WN>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, 0, nbx / P.tiles_m, by, 0,
+                                     nbx * nby, smem);
+}
+
+template <int BM, int BN, int NST, int NT = 256>
+__global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
+  __shared__ __attribute__((aligned(1024))) char smem[NST * (BM + BN) * 128];
+  conv_glds_body<BM, BN, NST, NT>(P, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
+}
+
+// Job-table form: several convolutions that do not depend on each other (the same-depth layers of an Inception
+// block's branches) as ONE grid.  map[2b], map[2b+1] = (job, block of that job's own grid[0] x grid[1]).
+template <int BM, int BN, int NST, int NT = 256>
+__global__ __launch_bounds__(NT) void conv_glds_jobs_kernel(const GemmParams* __restrict__ jobs,
+                                                            const int* __restrict__ map) {
+  __shared__ __attribute__((aligned(1024))) char smem[NST * (BM + BN) * 128];
+  const GemmParams& P = jobs[map[2 * blockIdx.x]];
+  const int lb = map[2 * blockIdx.x + 1];
+  const int nx = P.grid[0];
+  conv_glds_body<BM, BN, NST, NT>(P, lb % nx, lb / nx, nx, P.grid[1], smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -1667,6 +1685,9 @@ static void default_epilogue(GemmEpilogue& E) {
   E.alpha = 1.f;
 }
 
+// job: instead of launching, write the problem as a record for ried_conv2d_jobs (general kernel, 64 x 64 tiles)
+struct ConvJobOut { void* rec; int* nblocks; };
+
 // Conv2d forward (transposed = 0) or ConvTranspose2d forward / strided-conv data gradient
 // (transposed = 1).  x: NHWC bf16 [nimg][H][W][ldx], channels 0..Cin-1 used.
 // w: packed bf16 [Cout][kh][kw][Cin].  y: NHWC [nimg][Ho][Wo][ldy], channels 0..Cout-1 written.
@@ -1675,7 +1696,8 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                        int transposed, const float* bias, int act, float* stats, int accumulate, int out_f32,
                        float* y2, long long ldy2, const void* mask, long long ldmask, float mask_slope,
                        int stats_post, const BnFinalize* fin, hipStream_t stream, const float* sub = nullptr,
-                       long long ld_sub = 0, void* gout = nullptr, long long ld_gout = 0, float gscale = 0.f) {
+                       long long ld_sub = 0, void* gout = nullptr, long long ld_gout = 0, float gscale = 0.f,
+                       const ConvJobOut* job = nullptr) {
   RIED_CHECK_ARG(x && w && y, "ried_conv2d: null pointer");
   RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
   RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
@@ -1734,6 +1756,16 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                  "ried_conv2d: operand larger than 4 GiB");
   P.A_bytes = (unsigned)a_bytes; P.B_bytes = (unsigned)b_bytes;
   ConvTile t = choose_conv_tile(Cout, npix, phases, conv_ksteps(Cin, kh, kw, sh, sw, transposed), kh * kw);
+  if (job) {
+    RIED_CHECK_ARG(!fin && !img_stats && (!stats || P.E.stats_fold),
+                   "ried_conv2d_make_job: statistics must be the folded form (stats_post = 2)");
+    t.bm = 64; t.bn = 64; t.nst = 2;
+    P.tiles_m = ceil_div(Cout, t.bm);
+    P.grid[0] = P.tiles_m * ceil_div(npix, t.bn); P.grid[1] = phases; P.grid[2] = 1;
+    memcpy(job->rec, &P, sizeof(P));
+    *job->nblocks = P.grid[0] * P.grid[1];
+    return RIED_OK;
+  }
   // 3x3 stride-1 layers on maps of whole 16x16 tiles: the halo-tile kernel (the input tile serves all nine taps)
   if (g_forced_tile[0] == 0 && P.E.staged && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 &&
       Cin % 64 == 0 && H % 8 == 0 && W % 8 == 0 && a_bytes < 0xFFFF0000ll - 16384 && b_bytes < 0xFFFFF000ll - 1024 &&
@@ -1828,6 +1860,29 @@ extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y,
                            int stats_post, hipStream_t stream) {
   return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, bias, act,
                      stats, accumulate, out_f32, y2, ldy2, mask, ldmask, mask_slope, stats_post, nullptr, stream);
+}
+
+// Job-table form of ried_conv2d: convolutions that do not depend on each other in one launch of the general kernel
+// (64 x 64 tiles).  ried_conv2d_make_job() fills a HOST record (ried_conv2d_job_bytes() bytes; arguments as
+// ried_conv2d, statistics only in the folded form stats_post = 2) and reports the job's block count; the records are
+// copied to the device back to back and launched with ried_conv2d_jobs, map[2b], map[2b+1] = (job, block of the job).
+extern "C" int ried_conv2d_job_bytes(void) { return (int)sizeof(GemmParams); }
+extern "C" int ried_conv2d_make_job(void* job_host, const void* x, long long ldx, const void* w, void* y, long long ldy,
+                                    int nimg, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh,
+                                    int sw, int ph, int pw, int transposed, const float* bias, int act, float* stats,
+                                    int accumulate, int stats_post, int* nblocks) {
+  RIED_CHECK_ARG(job_host && nblocks, "ried_conv2d_make_job: null pointer");
+  ConvJobOut job{job_host, nblocks};
+  return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, bias, act,
+                     stats, accumulate, 0, nullptr, 0, nullptr, 0, 0.f, stats_post, nullptr, nullptr, nullptr, 0,
+                     nullptr, 0, 0.f, &job);
+}
+extern "C" int ried_conv2d_jobs(const void* jobs, const int* map, int nblocks, hipStream_t stream) {
+  RIED_CHECK_ARG(jobs && map && nblocks > 0, "ried_conv2d_jobs: bad arguments");
+  hipLaunchKernelGGL((conv_glds_jobs_kernel<64, 64, 2>), dim3(nblocks), dim3(256), 0, stream,
+                     (const GemmParams*)jobs, map);
+  RIED_CHECK_LAUNCH("ried_conv2d_jobs");
+  return RIED_OK;
 }
 
 // Convolution (or transposed convolution) of a BasicConv2d / BasicDeconv2d block (src/rinet.py:183-205) with the

@@ -500,8 +500,8 @@ class ConvBN:
             self.img_save = torch.empty(c.N * 2 * cout, dtype=F32, device=ctx.device)
         self.sliced = (BN_FOLD and ctx.training and self.raw.npix * cout <= BN_FOLD_MAX_ELEMS and not defer_apply
                        and not self.per_image)
-        if self.sliced:
-            self.stat_rows = min(self.stat_rows, ops.bn_fold_rows())
+        if self.sliced:        # every fold row exists: a job-table launch runs 64-pixel tiles, more than the layer's own
+            self.stat_rows = ops.bn_fold_rows()
         ctx.stats(self, "stats", self.stat_rows * 2 * cout, zeroed=self.sliced)
         self.fold = (torch.empty(ops.bn_finalize_fold_floats(cout), dtype=F32, device=ctx.device)
                      if self.stat_rows > 1024 else None)
@@ -545,20 +545,9 @@ class ConvBN:
         if self.sliced:
             if self.bn_fwd_grouped:      # normalised with its siblings by InputGradGroup.forward()
                 return
-            stats, rows, ldstat = self.stats, self.stat_rows, 0
-            if self.fused_fwd is not None:       # the sibling group's one convolution has produced raw and the sums
-                grp, c0 = self.fused_fwd
-                if self._gstats is None:
-                    self._gstats = grp.stats[c0:]
-                stats, rows, ldstat = self._gstats, grp.stat_rows, grp.total
-            else:
+            if self.fused_fwd is None:           # (else the sibling group's one convolution has produced raw and the sums)
                 c.conv(self.raw, stats=self.stats, stats_post=2)
-            ops.bn_apply_train(self.raw, self.out.v, stats, rows, self.save,
-                               st.p[self.bn + ".weight"], st.p[self.bn + ".bias"], st.b[self.bn + ".running_mean"],
-                               st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"], relu=self.act,
-                               accumulate=self.accumulate, ldstat=ldstat)
-            if self.bias_key:
-                ops.axpy_f32(st.b[self.bn + ".running_mean"], st.p[self.bias_key], 0.1)
+            self.forward_bn()
             return
         if ctx.training:
             stats, rows, ldstat = self.stats, self.stat_rows, 0
@@ -582,6 +571,77 @@ class ConvBN:
         ops.bn_apply(self.raw, self.out.v, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
                      relu=self.act, accumulate=self.accumulate)
 
+    def forward_bn(self):
+        """Small train-mode layers: statistics from the folded rows, normalisation and activation, in one launch."""
+        st = self.ctx.st
+        stats, rows, ldstat = self.stats, self.stat_rows, 0
+        if self.fused_fwd is not None:
+            grp, c0 = self.fused_fwd
+            if self._gstats is None:
+                self._gstats = grp.stats[c0:]
+            stats, rows, ldstat = self._gstats, grp.stat_rows, grp.total
+        ops.bn_apply_train(self.raw, self.out.v, stats, rows, self.save,
+                           st.p[self.bn + ".weight"], st.p[self.bn + ".bias"], st.b[self.bn + ".running_mean"],
+                           st.b[self.bn + ".running_var"], st.b[self.bn + ".num_batches_tracked"], relu=self.act,
+                           accumulate=self.accumulate, ldstat=ldstat)
+        if self.bias_key:
+            ops.axpy_f32(st.b[self.bn + ".running_mean"], st.p[self.bias_key], 0.1)
+
+    def backward_bn(self):
+        ctx, st = self.ctx, self.ctx.st
+        ops.bn_backward(self.out.g, self.raw, self.draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
+                        ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=self.act,
+                        accumulate=self.shared, folded=self.bfold if self.bwd_fold else None)
+
+    # ---- pieces for Par's level-wise job tables (small train-mode layers only) ----
+    def level_ok(self) -> bool:
+        return bool(self.ctx.training and self.sliced and not self.per_image and not self.bias_key
+                    and not self.defer_apply and not self.shared)
+
+    def fwd_conv_job(self, jobs: "ops.ConvJobs") -> bool:
+        """Add this layer's convolution to `jobs`; False when a sibling group's convolution has produced raw."""
+        if self.fused_fwd is not None:
+            return False
+        c = self.core
+        jobs.add(c.xin.v, c.wp, self.raw, c.kh, c.kw, c.sh, c.sw, c.ph, c.pw, transposed=c.deconv, stats=self.stats,
+                 stats_post=2)
+        return True
+
+    def fwd_bn_job(self):
+        """The layer's forward BatchNorm as a bn_apply_train_jobs record (None: a sibling group applies it)."""
+        if self.bn_fwd_grouped:
+            return None
+        st, bn = self.ctx.st, self.bn
+        stats_ptr, rows, ldstat = self.stats.data_ptr(), self.stat_rows, self.core.cout     # (the table takes no 0 = C)
+        if self.fused_fwd is not None:
+            grp, c0 = self.fused_fwd
+            stats_ptr, rows, ldstat = grp.stats.data_ptr() + 4 * c0, grp.stat_rows, grp.total
+        return ops.bn_apply_train_job(self.raw, self.out.v, stats_ptr, rows, ldstat, self.save,
+                                      st.b[bn + ".running_mean"], st.b[bn + ".running_var"],
+                                      st.b[bn + ".num_batches_tracked"], st.p[bn + ".weight"], st.p[bn + ".bias"],
+                                      act=self.act, accumulate=self.accumulate)
+
+    def bwd_bn_job(self):
+        """The layer's BatchNorm backward as a bn_backward_jobs record (None: a sibling group runs it)."""
+        if self.bn_bwd_grouped:
+            return None
+        st, bn = self.ctx.st, self.bn
+        if not self.bwd_fold and getattr(self, "_bn_scratch", None) is None:
+            self._bn_scratch = torch.empty(ops.bn_backward_scratch_floats(self.core.cout), dtype=F32,
+                                           device=self.ctx.device)
+        return ops.bn_backward_job(self.out.g, self.raw, self.draw, self.save, st.p[bn + ".weight"],
+                                   st.p[bn + ".bias"], None if self.bwd_fold else self._bn_scratch,
+                                   st.g[bn + ".weight"], st.g[bn + ".bias"], act=self.act, accumulate=self.shared,
+                                   folded=self.bfold if self.bwd_fold else None)
+
+    def bwd_dgrad_job(self, jobs: "ops.ConvJobs") -> bool:
+        c = self.core
+        if not c.need_dx:
+            return False
+        jobs.add(self.draw, c.wpt, c.xin.g, c.kh, c.kw, c.sh, c.sw, c.ph, c.pw, transposed=not c.deconv,
+                 accumulate=True)
+        return True
+
     def backward(self):
         """Reads out.g; writes weight / BN gradients; accumulates into xin.g when need_dx."""
         self.backward_local()
@@ -593,9 +653,7 @@ class ConvBN:
         draw = self.draw
         if self.bn_bwd_grouped:      # done for all siblings at once by InputGradGroup.backward()
             return
-        ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
-                        ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=self.act,
-                        accumulate=self.shared, folded=self.bfold if self.bwd_fold else None)
+        self.backward_bn()
         if self.bias_key:        # zero up to rounding in train mode, as in torch's autograd
             ops.colsum(draw, st.g[self.bias_key], ctx.f32s[self.lane])
         c.wgrad(draw)
@@ -737,6 +795,7 @@ FUSED_ATTN = not os.environ.get("RIED_NO_FUSED_ATTN")
 PACK_TILES = not os.environ.get("RIED_NO_PACK_TILES")
 FWD_BN_JOBS = not os.environ.get("RIED_NO_FWD_BN_JOBS")
 BN_BWD_FOLD = not os.environ.get("RIED_NO_BN_BWD_FOLD")
+LEVEL_JOBS = not os.environ.get("RIED_NO_LEVEL_JOBS")
 
 
 def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
@@ -892,6 +951,105 @@ class Par:
     def __init__(self, ctx: Ctx, branches: List[Seq]):
         assert 1 <= len(branches) <= N_LANES
         self.ctx, self.branches = ctx, branches
+        self.levels = None
+        if LEVEL_JOBS and ctx.grads and ctx.training and ctx.st is not None and not ctx.per_image:
+            ctx._late.append(self._build_levels)
+
+    # Level-wise execution (small train-mode layers).  The k-th layers of the branches do not depend on each other,
+    # and on small maps each is a short, latency-bound launch: their convolutions run as ONE job-table grid, their
+    # BatchNorms as another, forward and backward, on the caller's stream.  Layers the job tables do not take (pools,
+    # upsampling, large layers) run on their own in the same level order.
+    def _build_levels(self):
+        dev = self.ctx.device
+        depth = max(len(b.layers) for b in self.branches)
+        levels, worth = [], False
+        for k in range(depth):
+            items = [b.layers[k] for b in self.branches if k < len(b.layers)]
+            ok = [l for l in items if isinstance(l, ConvBN) and l.level_ok()]
+            rest = [l for l in items if not (isinstance(l, ConvBN) and l.level_ok())]
+            lv = {"rest": rest, "ok": ok, "k": k}
+            # forward: convolutions, then BatchNorms grouped by pixel count
+            fc = ops.ConvJobs()
+            lv["fwd_conv_single"] = []
+            convs = [l for l in ok if l.fused_fwd is None]
+            if len(convs) >= 2:
+                for l in convs:
+                    l.fwd_conv_job(fc)
+                fc.finalize(dev)
+                lv["fwd_conv"] = fc
+            else:
+                lv["fwd_conv"] = None
+                lv["fwd_conv_single"] = convs
+            lv["fwd_bn"], lv["fwd_bn_single"] = self._bn_tables(
+                [(l, l.fwd_bn_job()) for l in ok if not l.bn_fwd_grouped], dev)
+            # backward: BatchNorms, then data gradients (level 0: the branches' inputs are one tensor - one by one)
+            lv["bwd_bn"], lv["bwd_bn_single"] = self._bn_tables(
+                [(l, l.bwd_bn_job()) for l in ok if not l.bn_bwd_grouped], dev)
+            lv["bwd_all_folded"] = {n: all(l.bwd_fold for l in ok if not l.bn_bwd_grouped and l.raw.npix == n)
+                                    for n in lv["bwd_bn"]}
+            bc = ops.ConvJobs()
+            dgs = [l for l in ok if l.core.need_dx] if k > 0 else []
+            if len(dgs) >= 2:
+                for l in dgs:
+                    l.bwd_dgrad_job(bc)
+                bc.finalize(dev)
+                lv["bwd_conv"], lv["bwd_conv_single"] = bc, []
+            else:
+                lv["bwd_conv"], lv["bwd_conv_single"] = None, dgs
+            worth = worth or lv["fwd_conv"] is not None or bool(lv["fwd_bn"]) or bool(lv["bwd_bn"]) \
+                or lv["bwd_conv"] is not None
+            levels.append(lv)
+        if worth:
+            self.levels = levels
+
+    @staticmethod
+    def _bn_tables(pairs, dev):
+        """[(layer, record)] -> ({npix: (device table, njobs, maxC, minC)} for counts >= 2, [layers left alone])."""
+        by = {}
+        for l, row in pairs:
+            by.setdefault(l.raw.npix, []).append((l, row))
+        tables, singles = {}, []
+        for npix, lr in by.items():
+            if len(lr) >= 2:
+                cs = [l.core.cout for l, _ in lr]
+                tables[npix] = (torch.tensor([r for _, r in lr], dtype=torch.int64).to(dev), len(lr), max(cs), min(cs))
+            else:
+                singles += [l for l, _ in lr]
+        return tables, singles
+
+    def _forward_levels(self):
+        for lv in self.levels:
+            for l in lv["rest"]:
+                l.forward()
+            if lv["fwd_conv"] is not None:
+                lv["fwd_conv"].launch()
+            for l in lv["fwd_conv_single"]:
+                l.core.conv(l.raw, stats=l.stats, stats_post=2)
+            for npix, (table, n, maxc, minc) in lv["fwd_bn"].items():
+                ops.bn_apply_train_jobs(table, n, npix, maxc, minc)
+            for l in lv["fwd_bn_single"]:
+                l.forward_bn()
+
+    def _backward_levels(self):
+        for lv in reversed(self.levels):
+            first = lv["k"] == 0
+            for l in lv["rest"]:
+                if first:
+                    l.backward_local()
+                else:
+                    l.backward()
+            for npix, (table, n, maxc, minc) in lv["bwd_bn"].items():
+                ops.bn_backward_jobs(table, n, npix, maxc, lv["bwd_all_folded"][npix])
+            for l in lv["bwd_bn_single"]:
+                l.backward_bn()
+            for l in lv["ok"]:
+                l.core.wgrad(l.draw)           # (deferred to the grouped launch in every plan built here: a no-op)
+            if lv["bwd_conv"] is not None:
+                lv["bwd_conv"].launch()
+            for l in lv["bwd_conv_single"]:
+                l.backward_input()
+        for b in self.branches:
+            b.backward_input()
 
     def _run(self, fn_name: str):
         if os.environ.get("RIED_SERIAL_BRANCHES") or not PAR_BRANCHES:     # one stream (debugging aid; replica lanes)
@@ -909,9 +1067,13 @@ class Par:
             main.wait_stream(side_stream(lane))
 
     def forward(self):
+        if self.levels is not None:
+            return self._forward_levels()
         self._run("forward")
 
     def backward(self):
+        if self.levels is not None:
+            return self._backward_levels()
         self._run("backward_local")
         for b in self.branches:
             b.backward_input()

@@ -134,6 +134,38 @@ class WgradJobs:
             lib.ried_conv2d_wgrad_jobs(_p(jobs), _p(m), n, bm, bn, _stream())
 
 
+class ConvJobs:
+    """Convolutions that do not depend on each other, launched as one grid (ried_conv2d_jobs)."""
+
+    def __init__(self):
+        self.recs, self.counts = [], []
+        self.jobs = None
+
+    def add(self, x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed=False, bias=None, act=0,
+            stats=None, accumulate=False, stats_post=0):
+        """Arguments as conv2d (statistics only in the folded form, stats_post = 2)."""
+        import numpy as np
+        assert self.jobs is None
+        rec = np.zeros(lib.ried_conv2d_job_bytes(), dtype=np.uint8)
+        nb = np.zeros(1, dtype=np.int32)
+        lib.ried_conv2d_make_job(rec.ctypes.data, x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C,
+                                 kh, kw, sh, sw, ph, pw, int(transposed), _p(bias), act, _p(stats), int(accumulate),
+                                 int(stats_post), nb.ctypes.data)
+        self.recs.append(rec); self.counts.append(int(nb[0]))
+
+    def __len__(self):
+        return len(self.recs)
+
+    def finalize(self, device):
+        import numpy as np
+        self.jobs = torch.from_numpy(np.concatenate(self.recs)).to(device)
+        m = np.asarray([(j, b) for j, c in enumerate(self.counts) for b in range(c)], dtype=np.int32).reshape(-1)
+        self.map, self.nblocks = torch.from_numpy(m).to(device), sum(self.counts)
+
+    def launch(self):
+        lib.ried_conv2d_jobs(_p(self.jobs), _p(self.map), self.nblocks, _stream())
+
+
 def conv2d_wgrad_tiles(Cg, Cp) -> int:
     return lib.ried_conv2d_wgrad_tiles(Cg, Cp)
 
