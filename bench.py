@@ -45,52 +45,68 @@ def synth_states(seed=0):
 
 
 def instrumented_step(ts):
-    """One eager step with HIP events around every launch of the GEMM-family kernels."""
+    """One eager step with HIP events around every launch of the MFMA kernels (convolutions, weight gradients,
+    attention).  Returns (families, templates): time, flops and algorithmic bytes summed per kernel family and per
+    kernel template (the template a call runs comes from ried_conv2d_which / the tile rules of the weight gradient)."""
     from reid_gan_amd import ops
-    rec = []
-    orig = {k: getattr(ops, k) for k in ("conv2d", "conv2d_tap_mse", "conv2d_wgrad", "bgemm")}
+    rec = []            # (family, template, flops, bytes, event, event)
+    names = ("conv2d", "conv2d_tap_mse", "conv2d_wgrad", "bgemm", "attn_fwd", "attn_bwd")
+    orig = {k: getattr(ops, k) for k in names}
 
-    def wrap(name, fn, flops, nbytes=None):
-        def inner(*a, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            fn(*a, **kw)
-            e1.record()
-            rec.append((name, flops(*a, **kw), e0, e1, nbytes(*a, **kw) if nbytes else 0.0))
-        return inner
+    def timed(family, template, flops, nbytes, fn):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        rec.append((family, template, flops, nbytes, e0, e1))
 
-    def b_conv(x, w, y, kh, kw_, sh, sw, ph, pw, accumulate=False, y2=None, mask=None, **k):
+    def conv(x, w, y, kh, kw_, sh, sw, ph, pw, **k):
         """Algorithmic HBM bytes of one launch: each operand once (bf16), the fp32 tap copy, re-read on accumulate."""
-        b = 2.0 * (x.npix * x.C + w.numel() + y.npix * y.C * (2 if accumulate else 1))
-        if y2 is not None:
-            b += 4.0 * y.npix * y.C
-        if mask is not None:
-            b += 2.0 * y.npix * y.C
-        return b
+        nb = 2.0 * (x.npix * x.C + w.numel() + y.npix * y.C * (2 if k.get("accumulate") else 1))
+        if k.get("y2") is not None:
+            nb += 4.0 * y.npix * y.C
+        if k.get("mask") is not None:
+            nb += 2.0 * y.npix * y.C
+        fl = 2.0 * (x.npix if k.get("transposed") else y.npix) * x.C * y.C * kh * kw_
+        timed("conv", ops.conv2d_which(x, w, y, kh, kw_, sh, sw, ph, pw, **k), fl, nb,
+              lambda: orig["conv2d"](x, w, y, kh, kw_, sh, sw, ph, pw, **k))
 
-    def f_conv(x, w, y, kh, kw_, sh, sw, ph, pw, transposed=False, **k):
-        if transposed:
-            return 2.0 * x.npix * x.C * y.C * kh * kw_
-        return 2.0 * y.npix * y.C * x.C * kh * kw_
+    def tap(x, w, bias, y, target, gout, gscale, stats):      # x, w, y, gradient seed (bf16) + the fp32 target tap
+        nb = 2.0 * (x.npix * x.C + w.numel() + 2 * y.npix * y.C) + 4.0 * y.npix * y.C
+        timed("conv", ops.conv2d_which(x, w, y, 3, 3, 1, 1, 1, 1, bias=bias, act=1, stats=stats) + " +tap MSE",
+              2.0 * y.npix * y.C * x.C * 9, nb, lambda: orig["conv2d_tap_mse"](x, w, bias, y, target, gout, gscale, stats))
 
-    def f_tap(x, w, bias, y, target, gout, gscale, stats):
-        return 2.0 * y.npix * y.C * x.C * 9
+    def wgrad(g, p, kh, kw_, sh, sw, ph, pw, slab, splitk):
+        bm, bn = (64 if g.C <= 64 else 128), (64 if p.C <= 64 else 128)
+        nb = 2.0 * (g.npix * g.C + p.npix * p.C) + 4.0 * splitk * kh * kw_ * p.C * g.C
+        timed("wgrad", f"wgrad_glds_kernel<{bm},{bn},2>", 2.0 * p.npix * p.C * g.C * kh * kw_, nb,
+              lambda: orig["conv2d_wgrad"](g, p, kh, kw_, sh, sw, ph, pw, slab, splitk))
 
-    def b_tap(x, w, bias, y, target, gout, gscale, stats):      # x, w, y, gradient seed (bf16) + the fp32 target tap
-        return 2.0 * (x.npix * x.C + w.numel() + 2 * y.npix * y.C) + 4.0 * y.npix * y.C
+    def bgemm(A, lda, bsa, a_tr, B, ldb, bsb, b_tr, M, N, K, batch, *a, **k):
+        timed("attention", "igemm_kernel<*>", 2.0 * M * N * K * batch, 2.0 * batch * (M * K + N * K + M * N),
+              lambda: orig["bgemm"](A, lda, bsa, a_tr, B, ldb, bsb, b_tr, M, N, K, batch, *a, **k))
 
-    def f_wgrad(g, p, kh, kw_, sh, sw, ph, pw, slab, splitk):
-        return 2.0 * p.npix * p.C * g.C * kh * kw_
+    def attn_fwd(qkv, x, out, O, lse, gamma, d):
+        n, C, nimg = qkv.H * qkv.W, O.C, qkv.N
+        timed("attention", f"attn_fwd_kernel<{n},{d},{C}>", 2.0 * nimg * n * n * (d + C),
+              2.0 * nimg * n * (2 * d + 4 * C), lambda: orig["attn_fwd"](qkv, x, out, O, lse, gamma, d))
 
-    def f_bgemm(A, lda, bsa, a_tr, B, ldb, bsb, b_tr, M, N, K, batch, *a, **k):
-        return 2.0 * M * N * K * batch
+    def attn_bwd(qkv, dqkv, dout, O, lse_ptr, gamma, dgamma, d):
+        n, C, nimg = qkv.H * qkv.W, O.C, qkv.N
+        timed("attention", f"attn_bwd_kernel<{n},{d},{C}>", 2.0 * nimg * n * n * (3 * d + 2 * C),
+              2.0 * nimg * n * (4 * d + 4 * C), lambda: orig["attn_bwd"](qkv, dqkv, dout, O, lse_ptr, gamma, dgamma, d))
 
-    ops.conv2d = wrap("conv", orig["conv2d"], f_conv, b_conv)
-    ops.conv2d_tap_mse = wrap("conv", orig["conv2d_tap_mse"], f_tap, b_tap)
-    ops.conv2d_wgrad = wrap("wgrad", orig["conv2d_wgrad"], f_wgrad)
-    ops.bgemm = wrap("bgemm", orig["bgemm"], f_bgemm)
-    launch_jobs = ops.WgradJobs.launch           # the grouped weight-gradient launches of the generator
-    ops.WgradJobs.launch = wrap("wgrad", launch_jobs, lambda self: self.flops)
+    ops.conv2d, ops.conv2d_tap_mse, ops.conv2d_wgrad, ops.bgemm = conv, tap, wgrad, bgemm
+    ops.attn_fwd, ops.attn_bwd = attn_fwd, attn_bwd
+    launch_wj, launch_cj = ops.WgradJobs.launch, ops.ConvJobs.launch      # the grouped launches of the generator
+
+    def wj(self):
+        launch_wj(self, around=lambda bm, bn, fn: timed("wgrad", f"wgrad_glds_jobs_kernel<{bm},{bn},2>",
+                                                        self.group_flops[(bm, bn)], self.group_bytes[(bm, bn)], fn))
+
+    def cj(self):
+        timed("conv", "conv_glds_jobs_kernel<64,64,2>", self.flops, self.bytes, lambda: launch_cj(self))
+    ops.WgradJobs.launch, ops.ConvJobs.launch = wj, cj
     # kernels timed one at a time: no side streams while the events are in place
     saved = (ts.overlap_vgg, ts.overlap_gbwd, os.environ.get("RIED_SERIAL_BRANCHES"), ts.overlap_dreal)
     ts.overlap_vgg = ts.overlap_gbwd = ts.overlap_dreal = False
@@ -108,20 +124,38 @@ def instrumented_step(ts):
     finally:
         for k, v in orig.items():
             setattr(ops, k, v)
-        ops.WgradJobs.launch = launch_jobs
+        ops.WgradJobs.launch, ops.ConvJobs.launch = launch_wj, launch_cj
         ts.overlap_vgg, ts.overlap_gbwd, ts.overlap_dreal = saved[0], saved[1], saved[3]
         if saved[2] is None:
             del os.environ["RIED_SERIAL_BRANCHES"]
         else:
             os.environ["RIED_SERIAL_BRANCHES"] = saved[2]
-    fam = {}
-    for name, fl, e0, e1, nb in rec:
-        d = fam.setdefault(name, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
-        d["launches"] += 1
-        d["flops"] += fl
-        d["ms"] += e0.elapsed_time(e1)
-        d["bytes"] += nb
-    return fam
+    fam, tem = {}, {}
+    for family, template, fl, nb, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        for table, key in ((fam, family), (tem, template)):
+            d = table.setdefault(key, {"launches": 0, "flops": 0.0, "ms": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["flops"] += fl
+            d["ms"] += ms
+            d["bytes"] += nb
+    return fam, tem
+
+
+def _pmc_tables():
+    """Counter evidence committed under profiles/ (rocprofv3 --pmc passes over tools/step_prof.py): HBM bytes per launch
+    and MFMA-busy fraction per kernel name; the newest round's files win."""
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    traffic, busy = None, {}
+    for r in ("r02", "r01"):
+        f = os.path.join(root, f"{r}_pmc_conv_traffic.json")
+        if traffic is None and os.path.exists(f):
+            traffic = json.load(open(f))
+        f = os.path.join(root, f"{r}_pmc_mfma_busy.json")
+        if not busy and os.path.exists(f):
+            busy = {k.replace("void ", "").replace(" ", ""): v["mfma_busy_frac"]
+                    for k, v in json.load(open(f))["kernels"].items()}
+    return traffic, busy
 
 
 def cpu_baseline(budget_s=12.0):
@@ -458,26 +492,36 @@ def main():
     if args.size == 64:
         out["step_mfma_frac"] = value / world * FLOP_PER_PATCH_64 / PEAK_MFMA_BF16
     if rank == 0:
-        fam = instrumented_step(ts)
+        fam, tem = instrumented_step(ts)
         dom = max(fam, key=lambda k: fam[k]["ms"])
         a = fam[dom]["flops"] / (fam[dom]["ms"] * 1e-3)
-        names = {"conv": "conv_glds_kernel<*>, conv_halo_kernel<*>, conv_halo_s2t_kernel<*> (conv / transposed conv "
-                         "forward and data gradient)",
+        names = {"conv": "conv_glds_kernel<*>, conv_glds_jobs_kernel, conv_halo_kernel<*>, conv_halo_s2t_kernel, "
+                         "conv_halo_d4_kernel (conv / transposed conv forward and data gradient)",
                  "wgrad": "wgrad_glds_kernel / wgrad_glds_jobs_kernel<*> (weight gradient)",
-                 "bgemm": "igemm_kernel<*, PLAIN_*, PLAIN_*> (attention products)"}
+                 "attention": "attn_fwd_kernel / attn_bwd_kernel (fused self-attention)"}
         # HBM bytes per launch of the conv family from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as the
         # gfx950 correction for wide reads, + WRITE_SIZE); the algorithmic bytes per launch are reported beside it
-        traffic = None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_conv_traffic.json")
-        if dom == "conv" and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["traffic_MB_per_launch"] * 1e6
+        pmc_traffic, pmc_busy = _pmc_tables()
+        traffic = pmc_traffic["traffic_MB_per_launch"] * 1e6 if (dom == "conv" and pmc_traffic) else None
+        # per kernel template: launches and time per step, flop rate, algorithmic HBM rate, MFMA-busy (counter pass)
+        templates = []
+        for k, v in sorted(tem.items(), key=lambda kv: -kv[1]["ms"]):
+            key = k.split(" ")[0].replace(" ", "")
+            busy = next((b for n, b in pmc_busy.items() if n.startswith(key.rstrip(">")) or
+                         key.replace(",", ", ") in n), None)
+            templates.append({"kernel": k, "launches": v["launches"], "us": round(v["ms"] * 1e3, 1),
+                              "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                              "mfma_frac": round(v["flops"] / (v["ms"] * 1e-3) / PEAK_MFMA_BF16, 4),
+                              "hbm_gbs_algorithmic": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                              "mfma_busy_pmc": None if busy is None else round(busy, 4)})
         out["roofline"] = {"bound": "mfma", "kernel": names[dom], "achieved": a / 1e12, "peak": PEAK_MFMA_BF16 / 1e12,
                            "unit": "TFLOP/s", "frac": a / PEAK_MFMA_BF16, "traffic": traffic,
                            "algorithmic_bytes_per_launch": fam[dom]["bytes"] / fam[dom]["launches"],
                            "launches_per_step": fam[dom]["launches"], "ms_per_step": fam[dom]["ms"],
                            "families": {k: {"launches": v["launches"], "ms": round(v["ms"], 3),
                                             "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)}
-                                        for k, v in fam.items()}}
+                                        for k, v in fam.items()},
+                           "templates": templates}
     else:
         ts._run_eager()       # keep the collectives of the instrumented step matched on every rank
     if multi:

@@ -1686,7 +1686,9 @@ static void default_epilogue(GemmEpilogue& E) {
 }
 
 // job: instead of launching, write the problem as a record for ried_conv2d_jobs (general kernel, 64 x 64 tiles)
-struct ConvJobOut { void* rec; int* nblocks; };
+// which: instead of launching, report the kernel the call would take: {kind, bm, bn or tile side, stages} with kind
+// 0 = conv_glds_kernel, 1 = conv_halo_kernel, 2 = conv_halo_s2t_kernel, 3 = conv_halo_d4_kernel
+struct ConvJobOut { void* rec; int* nblocks; int* which; };
 
 // Conv2d forward (transposed = 0) or ConvTranspose2d forward / strided-conv data gradient
 // (transposed = 1).  x: NHWC bf16 [nimg][H][W][ldx], channels 0..Cin-1 used.
@@ -1756,7 +1758,8 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                  "ried_conv2d: operand larger than 4 GiB");
   P.A_bytes = (unsigned)a_bytes; P.B_bytes = (unsigned)b_bytes;
   ConvTile t = choose_conv_tile(Cout, npix, phases, conv_ksteps(Cin, kh, kw, sh, sw, transposed), kh * kw);
-  if (job) {
+  int* const which = job ? job->which : nullptr;
+  if (job && !which) {
     RIED_CHECK_ARG(!fin && !img_stats && (!stats || P.E.stats_fold),
                    "ried_conv2d_make_job: statistics must be the folded form (stats_post = 2)");
     t.bm = 64; t.bn = 64; t.nst = 2;
@@ -1780,6 +1783,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     if (img_stats) P.E.stats_img_tiles = (H / ts) * (W / ts);
     else if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = ntiles; }
     const dim3 hgrid(P.tiles_m * ntiles);
+    if (which) { which[0] = 1; which[1] = bm; which[2] = ts; which[3] = (bm == 64 && Cin == 64 && ts == 16) ? 1 : 2; return RIED_OK; }
     if (ts == 8) hipLaunchKernelGGL((conv_halo_kernel<64, 8>), hgrid, dim3(512), 0, stream, P);
     else if (bm == 64 && Cin == 64) hipLaunchKernelGGL((conv_halo_kernel<64, 16, 1>), hgrid, dim3(512), 0, stream, P);
     else if (bm == 64) hipLaunchKernelGGL((conv_halo_kernel<64, 16>), hgrid, dim3(512), 0, stream, P);
@@ -1797,6 +1801,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     if (img_stats) P.E.stats_img_tiles = (H / 16) * (W / 16);
     else if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * 256 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
     const dim3 hgrid(P.tiles_m * ntiles);
+    if (which) { which[0] = 2; which[1] = 64; which[2] = 16; which[3] = 0; return RIED_OK; }
     hipLaunchKernelGGL(conv_halo_s2t_kernel<16>, hgrid, dim3(512), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
     return RIED_OK;
@@ -1814,6 +1819,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     if (img_stats) P.E.stats_img_tiles = (H / 16) * (W / 16);
     else if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * 256 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
     const dim3 hgrid(P.tiles_m * ntiles);
+    if (which) { which[0] = 3; which[1] = bm; which[2] = 16; which[3] = 0; return RIED_OK; }
     if (bm == 32) hipLaunchKernelGGL(conv_halo_d4_kernel<32>, hgrid, dim3(512), 0, stream, P);
     else hipLaunchKernelGGL(conv_halo_d4_kernel<64>, hgrid, dim3(512), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
@@ -1826,6 +1832,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   }
   P.tiles_m = ceil_div(Cout, t.bm);
   dim3 grid(P.tiles_m * ceil_div(npix, t.bn), phases, 1);
+  if (which) { which[0] = 0; which[1] = t.bm; which[2] = t.bn; which[3] = t.nst; return RIED_OK; }
   if (fin) {
     P.E.fin = *fin;
     P.E.fin.nrows = phases * ceil_div(npix, t.bn);
@@ -1872,10 +1879,24 @@ extern "C" int ried_conv2d_make_job(void* job_host, const void* x, long long ldx
                                     int sw, int ph, int pw, int transposed, const float* bias, int act, float* stats,
                                     int accumulate, int stats_post, int* nblocks) {
   RIED_CHECK_ARG(job_host && nblocks, "ried_conv2d_make_job: null pointer");
-  ConvJobOut job{job_host, nblocks};
+  ConvJobOut job{job_host, nblocks, nullptr};
   return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, bias, act,
                      stats, accumulate, 0, nullptr, 0, nullptr, 0, 0.f, stats_post, nullptr, nullptr, nullptr, 0,
                      nullptr, 0, 0.f, &job);
+}
+// Which kernel a ried_conv2d call with these arguments runs (for reports): which[4] = {kind, bm, bn or tile side,
+// LDS stages}; kind 0 = conv_glds_kernel<bm, bn, stages>, 1 = conv_halo_kernel<bm, side, stages>,
+// 2 = conv_halo_s2t_kernel<side>, 3 = conv_halo_d4_kernel<bm>.  Nothing is launched.
+extern "C" int ried_conv2d_which(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H,
+                                 int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph,
+                                 int pw, int transposed, const float* bias, int act, float* stats, int accumulate,
+                                 int out_f32, float* y2, long long ldy2, const void* mask, long long ldmask,
+                                 float mask_slope, int stats_post, int* which) {
+  RIED_CHECK_ARG(which != nullptr, "ried_conv2d_which: null pointer");
+  ConvJobOut q{nullptr, nullptr, which};
+  return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, bias, act,
+                     stats, accumulate, out_f32, y2, ldy2, mask, ldmask, mask_slope, stats_post, nullptr, nullptr,
+                     nullptr, 0, nullptr, 0, 0.f, &q);
 }
 extern "C" int ried_conv2d_jobs(const void* jobs, const int* map, int nblocks, hipStream_t stream) {
   RIED_CHECK_ARG(jobs && map && nblocks > 0, "ried_conv2d_jobs: bad arguments");

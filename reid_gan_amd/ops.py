@@ -79,6 +79,21 @@ def conv2d(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed
                     _stream())
 
 
+def conv2d_which(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed=False, bias=None, act=0,
+                 stats=None, accumulate=False, out_f32=False, y2: Optional[torch.Tensor] = None,
+                 mask: Optional[View] = None, mask_slope=0.0, stats_post=False) -> str:
+    """Name of the kernel template a conv2d call with these arguments runs (for reports; nothing is launched)."""
+    import ctypes
+    which = (ctypes.c_int * 4)()
+    lib.ried_conv2d_which(x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C, kh, kw, sh, sw, ph, pw,
+                          int(transposed), _p(bias), act, _p(stats), int(accumulate), int(out_f32), _p(y2), y.C,
+                          None if mask is None else mask.ptr, 0 if mask is None else mask.ld, mask_slope,
+                          int(stats_post), ctypes.addressof(which))
+    kind, bm, bn, nst = list(which)
+    return (f"conv_glds_kernel<{bm},{bn},{nst}>", f"conv_halo_kernel<{bm},{bn},{nst}>", f"conv_halo_s2t_kernel<{bn}>",
+            f"conv_halo_d4_kernel<{bm}>")[kind]
+
+
 def conv2d_tap_mse(x: View, w: torch.Tensor, bias: torch.Tensor, y: View, target: torch.Tensor, gout: View,
                    gscale: float, stats: torch.Tensor):
     """VGG tap layer on the prediction images with the perceptual MSE against `target` (fp32, same shape as y,
@@ -110,6 +125,7 @@ class WgradJobs:
         self.groups = {}           # (bm, bn) -> [records], [block counts]
         self.dev = []
         self.flops = 0.0           # 2 * pixels * Cg * Cp * taps over all jobs (for reporting)
+        self.group_flops, self.group_bytes = {}, {}
 
     def add(self, g: View, p: View, kh, kw, sh, sw, ph, pw, slab_ptr: int, splitk: int):
         import numpy as np
@@ -120,6 +136,10 @@ class WgradJobs:
         recs, counts = self.groups.setdefault((int(tile[0]), int(tile[1])), ([], []))
         recs.append(rec); counts.append(int(nb[0]))
         self.flops += 2.0 * p.npix * p.C * g.C * kh * kw
+        key = (int(tile[0]), int(tile[1]))
+        self.group_flops[key] = self.group_flops.get(key, 0.0) + 2.0 * p.npix * p.C * g.C * kh * kw
+        self.group_bytes[key] = (self.group_bytes.get(key, 0.0) + 2.0 * (g.npix * g.C + p.npix * p.C)
+                                 + 4.0 * splitk * kh * kw * p.C * g.C)
 
     def finalize(self, device):
         import numpy as np
@@ -129,9 +149,14 @@ class WgradJobs:
             m = np.asarray([(j, b) for j, c in enumerate(counts) for b in range(c)], dtype=np.int32).reshape(-1)
             self.dev.append((bm, bn, jobs, torch.from_numpy(m).to(device), sum(counts)))
 
-    def launch(self):
+    def launch(self, around=None):
+        """around(bm, bn, fn): reporting hook that runs fn (one tile shape's launch) between its own timers."""
         for bm, bn, jobs, m, n in self.dev:
-            lib.ried_conv2d_wgrad_jobs(_p(jobs), _p(m), n, bm, bn, _stream())
+            fn = lambda: lib.ried_conv2d_wgrad_jobs(_p(jobs), _p(m), n, bm, bn, _stream())
+            if around is None:
+                fn()
+            else:
+                around(bm, bn, fn)
 
 
 class ConvJobs:
@@ -140,6 +165,7 @@ class ConvJobs:
     def __init__(self):
         self.recs, self.counts = [], []
         self.jobs = None
+        self.flops = self.bytes = 0.0      # 2 * pixels * Cin * Cout * taps, and each operand once (for reporting)
 
     def add(self, x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed=False, bias=None, act=0,
             stats=None, accumulate=False, stats_post=0):
@@ -152,6 +178,8 @@ class ConvJobs:
                                  kh, kw, sh, sw, ph, pw, int(transposed), _p(bias), act, _p(stats), int(accumulate),
                                  int(stats_post), nb.ctypes.data)
         self.recs.append(rec); self.counts.append(int(nb[0]))
+        self.flops += 2.0 * (x.npix if transposed else y.npix) * x.C * y.C * kh * kw
+        self.bytes += 2.0 * (x.npix * x.C + w.numel() + y.npix * y.C * (2 if accumulate else 1))
 
     def __len__(self):
         return len(self.recs)
