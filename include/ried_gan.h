@@ -131,8 +131,8 @@ int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp, int Cg, f
  *     dst_f32 == 2, a tile job: words src, dst1, sigma, A, B, T, dst2 - the master is [A][B][T] (T <= 16; A, B even)
  *     and is written as dst1 [A][T][B] and dst2 [B][T][A] (bf16, either may be 0): both packed layouts of a
  *     convolution weight from one read of it; blockmap chunk = tile (a / 32) * ceil(B / 32) + b / 32.
- *   reduce job (11 words): slab, out, splitk, split_stride, taps, Cp, Cg, st, sp, sg, accumulate - as
- *     ried_wgrad_reduce with scale 1 and slab[k*split_stride + (tap*Cp + p)*Cg + g]. */
+ *   reduce job (12 words): slab, out, splitk, split_stride, taps, Cp, Cg, st, sp, sg, accumulate, scale (the bits of
+ *     an fp32 number; 0 means 1.0) - as ried_wgrad_reduce with slab[k*split_stride + (tap*Cp + p)*Cg + g]. */
 int ried_pack_jobs(const long long* jobs, const int* blockmap, int nblocks, ried_stream_t stream);
 int ried_wgrad_reduce_jobs(const long long* jobs, const int* blockmap, int nblocks, ried_stream_t stream);
 

@@ -195,9 +195,9 @@ extern "C" int ried_pack_jobs(const long long* jobs, const int* blockmap, int nb
   return RIED_OK;
 }
 
-#define WRED_JOB_WORDS 11
-// reduce job: slab, out, splitk, split_stride, taps, Cp, Cg, st, sp, sg, accumulate
-//   out[tap*st + p*sp + g*sg] (+)= sum_k slab[k*split_stride + (tap*Cp + p)*Cg + g]
+#define WRED_JOB_WORDS 12
+// reduce job: slab, out, splitk, split_stride, taps, Cp, Cg, st, sp, sg, accumulate, scale (fp32 bits; 0 = 1.0)
+//   out[tap*st + p*sp + g*sg] (+)= scale * sum_k slab[k*split_stride + (tap*Cp + p)*Cg + g]
 // blockmap[b] = (job, p): one block per output row p.  The slab is read in its own order (g fastest) and the row
 // is transposed through LDS so that masters whose row is laid out [g][tap] (st == 1, sg == taps: every conv,
 // deconv and attention weight) are written as one contiguous run; other layouts fall back to scattered stores.
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const long long*
   float* out = (float*)J[1];
   const int splitk = (int)J[2], taps = (int)J[4], Cp = (int)J[5], Cg = (int)J[6];
   const long long stride = J[3], st = J[7], sp = J[8], sg = J[9];
+  const float scale = J[11] ? __int_as_float((int)J[11]) : 1.f;
   const int E = taps * Cg;
   const bool contiguous = st == 1 && sg == taps && E <= WRED_MAX_ROW;
   // 256 threads = Ew four-element groups x KT lanes over the splits (short rows would otherwise leave most threads
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_jobs_kernel(const long long*
     if (live && kl == 0) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        acc[q] *= scale;
         if (contiguous) rowbuf[(g + q) * taps + tap] = acc[q];
         else {
           float* o = out + tap * st + p * sp + (g + q) * sg;

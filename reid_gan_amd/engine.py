@@ -131,6 +131,7 @@ class Ctx:
         self.dx_group: Optional["InputGradGroup"] = None     # open group of sibling 1x1 layers (see InputGradGroup)
         self.build_lane = 0                # lane (stream + scratch set) the layers being built will run on
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
+        self.nine: Optional[torch.Tensor] = None      # device scalar 9.0 (divisor of the pool-folded weights)
         self.sn = ops.SnJobs()             # every spectral-norm layer: power iteration / sigma gradient per launch
         # Deferred weight gradients (one launch per tile shape) and the reduction of their split-K slabs (one launch),
         # issued by end_backward().  One pair of tables per gradient bucket: with data parallelism a network's
@@ -146,7 +147,7 @@ class Ctx:
         """Layers built from here on put their weight gradients into bucket b."""
         while len(self._wgrads_all) <= b:
             self._wgrads_all.append(ops.WgradJobs())
-            self._wreds_all.append(ops.JobTable(11))
+            self._wreds_all.append(ops.JobTable(12))
         self.bucket = b
         self.wgrads, self.wreds = self._wgrads_all[b], self._wreds_all[b]
 
@@ -199,9 +200,12 @@ class Ctx:
                         A, B, T, 0 if dst2 is None else dst2.data_ptr(), 0, 0, 0, 0, 0, 2],
                        nblocks=((A + 31) // 32) * ((B + 31) // 32))
 
-    def add_wgrad_reduce(self, slab_off, out: torch.Tensor, splitk, taps, Cp, Cg, st, sp, sg, accumulate=False):
-        j = self.wreds.add([0, out.data_ptr(), splitk, taps * Cp * Cg, taps, Cp, Cg, st, sp, sg, int(accumulate)],
-                           nblocks=Cp)
+    def add_wgrad_reduce(self, slab_off, out: torch.Tensor, splitk, taps, Cp, Cg, st, sp, sg, accumulate=False,
+                         split_stride=None, scale=None):
+        import struct
+        bits = 0 if scale is None else struct.unpack("<i", struct.pack("<f", scale))[0] & 0xFFFFFFFF
+        j = self.wreds.add([0, out.data_ptr(), splitk, taps * Cp * Cg if split_stride is None else split_stride, taps,
+                            Cp, Cg, st, sp, sg, int(accumulate), bits], nblocks=Cp)
         self._wred_slab.append((self.wreds, j, slab_off))
 
     def need_tmp(self, n):
@@ -373,10 +377,21 @@ class ConvCore:
 
     def __init__(self, ctx: Ctx, wname: str, cin, cout, k, stride, pad, deconv: bool, xin: Slot, need_dx: bool,
                  need_wgrad: bool = True, sigma: Optional[torch.Tensor] = None,
-                 wgrad_out: Optional[torch.Tensor] = None):
+                 wgrad_out: Optional[torch.Tensor] = None, pool_fold: bool = False):
         """sigma: device scalar the packed weights are divided by (spectral norm); wgrad_out: where the reduced
-        weight gradient goes (master layout; default: the parameter's slot in the state's gradient buffer)."""
+        weight gradient goes (master layout; default: the parameter's slot in the state's gradient buffer).
+        pool_fold: the layer is avg_pool2d(3, 1, 1) followed by a 1x1 convolution (the branch_pool of Inception A / C /
+        E, src/rinet.py:234,250-251 and alike).  With count_include_pad (the default) that is exactly a 3x3
+        convolution, zero padding, whose nine taps all hold W / 9: k = 3, pad = 1 here, the master weight stays
+        (Cout, Cin, 1, 1); the packed copies replicate it over the taps and the weight gradient sums the taps' slabs
+        (times 1/9).  No pooled tensor is written or read, forward or backward."""
         self.ctx, self.wname = ctx, wname
+        self.pool_fold = pool_fold
+        if pool_fold:
+            assert _pair(k) == (3, 3) and _pair(stride) == (1, 1) and _pair(pad) == (1, 1) and not deconv
+            if ctx.nine is None:
+                ctx.nine = torch.full((1,), 9.0, dtype=F32, device=ctx.device)
+            sigma = ctx.nine
         self.cin, self.cout = cin, cout
         self.kh, self.kw = _pair(k)
         self.sh, self.sw = _pair(stride)
@@ -401,13 +416,20 @@ class ConvCore:
             self.splitk = _splitk(ops.conv2d_wgrad_tiles(cg, cp) * taps, kp)
             self.slab_off = ctx.alloc_slab(self.splitk * taps * cin * cout)
             out = ctx.st.g[wname] if wgrad_out is None else wgrad_out
-            if deconv:    # slab [taps][Cp=cin][Cg=cout] -> master (Cin,Cout,kh,kw)
+            if pool_fold: # slab [splitk][9][Cp=cout][Cg=cin]: (split, tap) is one reduction axis -> master (Cout,Cin,1,1)
+                ctx.add_wgrad_reduce(self.slab_off, out, self.splitk * taps, 1, cout, cin, 1, cin, 1,
+                                     split_stride=cout * cin, scale=1.0 / 9.0)
+            elif deconv:  # slab [taps][Cp=cin][Cg=cout] -> master (Cin,Cout,kh,kw)
                 ctx.add_wgrad_reduce(self.slab_off, out, self.splitk, taps, cin, cout, 1, cout * taps, taps)
             else:         # slab [taps][Cp=cout][Cg=cin] -> master (Cout,Cin,kh,kw)
                 ctx.add_wgrad_reduce(self.slab_off, out, self.splitk, taps, cout, cin, 1, cin * taps, taps)
         if ctx.st is not None:
             w, t, kh, kw = ctx.st.p[wname], taps, self.kh, self.kw
-            if t <= 16 and cin % 2 == 0 and cout % 2 == 0 and PACK_TILES:     # both layouts from one read of the master
+            if pool_fold:   # master (Cout,Cin,1,1) / 9 into every tap of [Cout][3][3][Cin] and of [Cin][3][3][Cout]
+                ctx.add_pack(w, self.wp, cout, kh, kw, cin, cin, 0, 0, 1, sigma)
+                if self.wpt is not None:
+                    ctx.add_pack(w, self.wpt, cin, kh, kw, cout, 1, 0, 0, cin, sigma)
+            elif t <= 16 and cin % 2 == 0 and cout % 2 == 0 and PACK_TILES:     # both layouts from one read of the master
                 if deconv:
                     ctx.add_pack_pair(w, self.wpt, self.wp, cin, cout, t, sigma)
                 else:
@@ -465,7 +487,7 @@ class ConvBN:
 
     def __init__(self, ctx: Ctx, prefix: str, cin, cout, k, stride, pad, xin: Slot, out: Slot, deconv=False,
                  accumulate=False, need_dx=True, conv_key=None, bn_key=None, bias=False, act=1, shared=False,
-                 wgrad_out: Optional[torch.Tensor] = None, defer_apply=False):
+                 wgrad_out: Optional[torch.Tensor] = None, defer_apply=False, pool_fold=False):
         """bias / act / shared / wgrad_out serve the legacy networks (src/networks.py:466-542): a conv bias in front
         of the BatchNorm (train mode: it only shifts running_mean), the activation code of ops.bn_apply, layers
         applied several times per forward (BatchNorm and bias gradients then add onto the state's), and a
@@ -481,7 +503,7 @@ class ConvBN:
         fwd_member = (grp is not None and not ctx.grads and not defer_apply and not bias
                       and grp.wants(xin, k, stride, pad))      # forward-only plans: the group shares the convolution
         self.core = ConvCore(ctx, conv_key + ".weight", cin, cout, k, stride, pad, deconv, xin,
-                             need_dx and not grouped, wgrad_out=wgrad_out)
+                             need_dx and not grouped, wgrad_out=wgrad_out, pool_fold=pool_fold)
         c = self.core
         assert out.shape == (c.N, c.Ho, c.Wo, cout), (prefix, out.shape, (c.N, c.Ho, c.Wo, cout))
         self.out, self.accumulate = out, accumulate
@@ -796,6 +818,7 @@ PACK_TILES = not os.environ.get("RIED_NO_PACK_TILES")
 FWD_BN_JOBS = not os.environ.get("RIED_NO_FWD_BN_JOBS")
 BN_BWD_FOLD = not os.environ.get("RIED_NO_BN_BWD_FOLD")
 LEVEL_JOBS = not os.environ.get("RIED_NO_LEVEL_JOBS")
+POOL_FOLD = not os.environ.get("RIED_NO_POOL_FOLD")
 
 
 def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
@@ -1124,6 +1147,23 @@ def _chain(ctx: Ctx, seq: Seq, prefix: str, specs, xin: Slot, out: Slot, deconv=
     return cur
 
 
+def _pool_branch(ctx, seq, prefix, xin: Slot, out_slice: Slot, cin, cout):
+    """branch_pool = avg_pool2d(3, 1, 1) -> BasicConv2d 1x1 (src/rinet.py:234,250-251; 320,344-345; 416,441-442), added
+    onto the block output.  Forward-only plans fold it into one 3x3 convolution where the halo-tile kernel takes it
+    (see ConvCore.pool_fold): no pooled tensor, 5.32 -> 5.25 ms per batch of 32 slices of 512 x 512.  Training plans
+    keep the pool and the 1x1 layer: there the 3x3 form's nine-tap data and weight gradients cost more than the two
+    pool launches they replace (measured 7.89 -> 8.07 ms per step; RIED_POOL_FOLD_TRAIN=1 turns it on, the parity
+    tests pass either way)."""
+    N, H, W, _ = xin.shape
+    if POOL_FOLD and cin % 64 == 0 and (not ctx.grads or os.environ.get("RIED_POOL_FOLD_TRAIN")):
+        seq.add(ConvBN(ctx, prefix + ".branch_pool", cin, cout, 3, 1, 1, xin, out_slice, accumulate=True,
+                       pool_fold=True))
+        return
+    pooled = Slot(ctx.act(N, H, W, cin))
+    seq.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
+    _chain(ctx, seq, prefix, [("branch_pool", cin, cout, 1, 1, 0)], pooled, out_slice, accumulate=True)
+
+
 def _residual_head(ctx, seq, prefix, xin: Slot, out: Slot, cin, cout, has_ds):
     if has_ds:   # identity_downsample = Conv1x1 + BN + ReLU (src/rinet.py:99-103)
         seq.add(ConvBN(ctx, prefix + ".identity_downsample", cin, cout, 1, 1, 0, xin, out,
@@ -1147,10 +1187,7 @@ def inception_a(ctx, prefix, xin: Slot, out: Slot, cin, has_ds) -> Seq:
     with _Lane(ctx, 2) as b2:
         _chain(ctx, b2, prefix, [("branch1x1", cin, 32, 1, 1, 0)], xin, out.sub(0, 32), accumulate=True)
     with _Lane(ctx, 3) as b3:
-        N, H, W, _ = xin.shape
-        pooled = Slot(ctx.act(N, H, W, cin))
-        b3.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
-        _chain(ctx, b3, prefix, [("branch_pool", cin, 16, 1, 1, 0)], pooled, out.sub(112, 128), accumulate=True)
+        _pool_branch(ctx, b3, prefix, xin, out.sub(112, 128), cin, 16)
     s.add(Par(ctx, [b0, b1, b2, b3]))
     close_input_grad_group(grp, s)
     return s
@@ -1172,10 +1209,7 @@ def inception_c(ctx, prefix, xin: Slot, out: Slot, cin, c7, has_ds) -> Seq:
     with _Lane(ctx, 2) as b2:
         _chain(ctx, b2, prefix, [("branch1x1", cin, 64, 1, 1, 0)], xin, out.sub(0, 64), accumulate=True)
     with _Lane(ctx, 3) as b3:
-        N, H, W, _ = xin.shape
-        pooled = Slot(ctx.act(N, H, W, cin))
-        b3.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
-        _chain(ctx, b3, prefix, [("branch_pool", cin, 64, 1, 1, 0)], pooled, out.sub(192, 256), accumulate=True)
+        _pool_branch(ctx, b3, prefix, xin, out.sub(192, 256), cin, 64)
     s.add(Par(ctx, [b0, b1, b2, b3]))
     close_input_grad_group(grp, s)
     return s
@@ -1203,9 +1237,7 @@ def inception_e(ctx, prefix, xin: Slot, out: Slot, cin, has_ds) -> Seq:
     with _Lane(ctx, 2) as b2:
         _chain(ctx, b2, prefix, [("branch1x1", cin, 160, 1, 1, 0)], xin, out.sub(0, 160), accumulate=True)
     with _Lane(ctx, 3) as b4:
-        pooled = Slot(ctx.act(N, H, W, cin))
-        b4.add(Pool(ctx, ops.POOL_AVG3, xin, pooled))
-        _chain(ctx, b4, prefix, [("branch_pool", cin, 96, 1, 1, 0)], pooled, out.sub(928, 1024), accumulate=True)
+        _pool_branch(ctx, b4, prefix, xin, out.sub(928, 1024), cin, 96)
     s.add(Par(ctx, [b0, b1, b2, b4]))
     close_input_grad_group(grp, s)
     return s

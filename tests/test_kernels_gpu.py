@@ -438,7 +438,7 @@ def test_maxpool_bwd_overwrite_and_relu_mask():
 def test_job_table_pack_and_reduce_match_single_calls():
     """One launch over a job table = the per-layer calls."""
     g = torch.Generator().manual_seed(5)
-    jobs_p, jobs_r = ops.JobTable(13), ops.JobTable(11)
+    jobs_p, jobs_r = ops.JobTable(13), ops.JobTable(12)
     keep, checks = [], []
     sigma = torch.tensor([1.7], device=DEV)
     for n, (co, ci, kh, kw) in enumerate([(64, 32, 3, 3), (96, 192, 4, 4), (8, 8, 1, 1), (520, 24, 1, 7)]):
@@ -455,14 +455,14 @@ def test_job_table_pack_and_reduce_match_single_calls():
         oref = torch.zeros(co, ci, kh, kw, device=DEV)
         ogot = torch.full_like(oref, 0.5)
         ops.wgrad_reduce(slab, splitk, t, co, ci, oref, 1, ci * t, t)
-        jobs_r.add([slab.data_ptr(), ogot.data_ptr(), splitk, t * co * ci, t, co, ci, 1, ci * t, t, 0], nblocks=co)
+        jobs_r.add([slab.data_ptr(), ogot.data_ptr(), splitk, t * co * ci, t, co, ci, 1, ci * t, t, 0, 0], nblocks=co)
         keep += [w, slab]
         checks += [(ref, got), (oref, ogot)]
     # a master laid out [tap][p][g] (not the [p][g][tap] rows of conv weights): the scattered-store path
     slab = torch.randn(5, 4, 24, 40, generator=g).to(DEV)
     oref, ogot = torch.zeros(4, 24, 40, device=DEV), torch.full((4, 24, 40), 0.25, device=DEV)
     ops.wgrad_reduce(slab, 5, 4, 24, 40, oref, 24 * 40, 40, 1)
-    jobs_r.add([slab.data_ptr(), ogot.data_ptr(), 5, 4 * 24 * 40, 4, 24, 40, 24 * 40, 40, 1, 0], nblocks=24)
+    jobs_r.add([slab.data_ptr(), ogot.data_ptr(), 5, 4 * 24 * 40, 4, 24, 40, 24 * 40, 40, 1, 0, 0], nblocks=24)
     keep.append(slab); checks.append((oref, ogot))
     # an fp32 destination with a row pitch (a [rows][pitch] matrix filled in column blocks)
     src = torch.randn(40, 24, generator=g).to(DEV)
