@@ -105,6 +105,14 @@ int ried_conv2d_wgrad_jobs(const void* jobs, const int* map, int nblocks, int bm
  * HOST record of ried_conv2d_job_bytes() bytes (arguments as ried_conv2d; statistics only in the folded form,
  * stats_post = 2) and reports the job's block count; records are copied to the device back to back and launched
  * with ried_conv2d_jobs, map[2b], map[2b+1] = (job, block of that job) for b < nblocks. */
+/* ried_conv2d for a consumer of a BasicConv2d layer (src/rinet.py:183-205, chains such as rinet.py:325-347): x is
+ * that layer's RAW convolution output, and the kernel applies the layer's train-mode BatchNorm (xf_save = [2][Cin]:
+ * mean, 1/sqrt(var + eps); xf_gamma, xf_beta) and activation (xf_act: 0 none, 1 ReLU) to the operand on its way
+ * through LDS: the normalised tensor is never written or read.  General kernel only, Cin <= 1024. */
+int ried_conv2d_xf(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W, int Cin,
+                   int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
+                   const float* bias, int act, float* stats, int accumulate, int stats_post, const float* xf_save,
+                   const float* xf_gamma, const float* xf_beta, int xf_act, ried_stream_t stream);
 int ried_conv2d_job_bytes(void);
 int ried_conv2d_make_job(void* job_host, const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg,
                          int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,

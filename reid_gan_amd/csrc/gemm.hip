@@ -79,6 +79,14 @@ struct GemmParams {
   int tiles_m;
   unsigned A_bytes, B_bytes;   // extent of the operands in bytes (buffer descriptors of the LDS-DMA kernel)
   int grid[3];                 // the problem's own grid (job-table launches)
+  // Input transform of the convolution kernel (xf_save != null): the B operand is the RAW output of a BasicConv2d
+  // layer's convolution and the kernel applies that layer's train-mode BatchNorm and activation on the fly,
+  // x -> act(gamma * (x - mean) * invstd + beta), with xf_save = [2][K] (mean, invstd), so that the normalised
+  // tensor is never written or read.  Padding stays zero (it pads the activated tensor).
+  const float* xf_save;
+  const float* xf_gamma;
+  const float* xf_beta;
+  int xf_act;                  // 0 none, 1 ReLU
 };
 
 constexpr int BK = 64;                            // k per stage: two MFMA k-slices of 32
@@ -774,8 +782,9 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned byt
 
 // NT threads: 256 (2 x 2 waves) or 512 (2 x 4 waves: twice the pixels per block for the same weight traffic).
 // (bx, by) of (nbx, nby): the block's place in the problem's own grid (the launch grid, or a job's share of one)
-template <int BM, int BN, int NST, int NT>
+template <int BM, int BN, int NST, int NT, bool XF = false>
 __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int by, int nbx, int nby, char* smem) {
+  static_assert(!XF || NST == 3, "the input transform works one stage ahead of the matrix products");
   constexpr int WN = NT / 128;                        // waves along the pixel axis
   constexpr int RPP = NT / 8;                         // rows per DMA pass (8 lanes = one 128-byte row)
   constexpr int TM = BM / 32, TN = BN / (16 * WN);
@@ -838,6 +847,18 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
 
   char* const lds_wave = smem + wave * 1024;            // + i * NT * 16 per row pass, + BM * 128 for B
   const unsigned ldx2 = (unsigned)X.ld * 2u;
+  // input transform: per-channel (scale, shift) table behind the stages; the chunk state of the stage in flight
+  float* const xf_ab = reinterpret_cast<float*>(smem + NST * STAGE);      // [2][K]
+  int xf_c = 0, xf_c_prev = 0;           // chunk state of the newest stage issued and of the one before it
+  unsigned xf_bad = 0, xf_bad_prev = 0;
+  if constexpr (XF) {
+    for (int ch = tid; ch < P.K; ch += NT) {
+      const float a = P.xf_gamma[ch] * P.xf_save[P.K + ch];
+      xf_ab[ch] = a;
+      xf_ab[P.K + ch] = P.xf_beta[ch] - P.xf_save[ch] * a;
+    }
+    __syncthreads();
+  }
 
   // Offsets are 16-byte aligned, so OR-ing GLDS_OOB into one leaves it out of range whatever its value: validity
   // is carried as a mask (0 or GLDS_OOB) and never as a branch around a load, which keeps the number of DMA
@@ -851,11 +872,13 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
     for (int i = 0; i < NLA; ++i) glds16(rsA, (wrow[i] + wk) | inval, dst + i * (NT * 16));
     const int dpx = dir * (ti * X.W + tj);
     const unsigned cb = (unsigned)c * 16u;
+    if constexpr (XF) { xf_c_prev = xf_c; xf_bad_prev = xf_bad; xf_c = c * 8; xf_bad = 0; }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
       int hi = gy[i] + dir * ti, wi = gx[i] + dir * tj;
       unsigned bad = ((unsigned)hi < (unsigned)X.H && (unsigned)wi < (unsigned)X.W) ? 0u : GLDS_OOB;
       glds16(rsB, ((unsigned)(pix[i] + dpx) * ldx2 + cb) | bad | inval, dst + BM * 128 + i * (NT * 16));
+      if constexpr (XF) xf_bad |= ((bad | inval) ? 1u : 0u) << i;
     }
     c += 8;
     while (c >= CPT) {
@@ -890,9 +913,41 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
   };
 
+  // Input transform: this lane's own chunks of stage `buf` have landed; normalise and activate them in place (the
+  // chunks of padding pixels and of the K tail hold the DMA's zeros and stay zero).  It runs one stage AHEAD of the
+  // matrix products, right after they are issued, so the vector work overlaps the matrix pipe; the next barrier
+  // publishes the result.
+  auto xf_stage = [&](int buf) {
+    float sc[8], sh[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sc[q] = xf_ab[xf_c_prev + q]; sh[q] = xf_ab[P.K + xf_c_prev + q]; }
+    char* const own = lds_wave + buf * STAGE + BM * 128 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      if (!((xf_bad_prev >> i) & 1u)) {
+        u32x4 v = *reinterpret_cast<u32x4*>(own + i * (NT * 16));
+        float f0 = bflo(v[0]) * sc[0] + sh[0], f1 = bfhi(v[0]) * sc[1] + sh[1];
+        float f2 = bflo(v[1]) * sc[2] + sh[2], f3 = bfhi(v[1]) * sc[3] + sh[3];
+        float f4 = bflo(v[2]) * sc[4] + sh[4], f5 = bfhi(v[2]) * sc[5] + sh[5];
+        float f6 = bflo(v[3]) * sc[6] + sh[6], f7 = bfhi(v[3]) * sc[7] + sh[7];
+        if (P.xf_act == 1) {
+          f0 = fmaxf(f0, 0.f); f1 = fmaxf(f1, 0.f); f2 = fmaxf(f2, 0.f); f3 = fmaxf(f3, 0.f);
+          f4 = fmaxf(f4, 0.f); f5 = fmaxf(f5, 0.f); f6 = fmaxf(f6, 0.f); f7 = fmaxf(f7, 0.f);
+        }
+        *reinterpret_cast<u32x4*>(own + i * (NT * 16)) =
+            u32x4{pack2bf(f0, f1), pack2bf(f2, f3), pack2bf(f4, f5), pack2bf(f6, f7)};
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
   // prologue: NST-1 stages in flight (stages past the end of K fetch zeros: uniform counts)
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) issue(s);
+  if constexpr (XF) {       // stage 0 has no earlier step to be transformed in
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");
+    xf_stage(0);
+  }
   int rd = 0, wr = NST - 1;
   for (int step = 0; step < nsteps; ++step) {
     // the DMA of stage `step` has landed for this wave's loads once at most NST-2 later stages are outstanding;
@@ -906,6 +961,10 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
     mfmas(1);
     rd = rd + 1 == NST ? 0 : rd + 1;
     wr = wr + 1 == NST ? 0 : wr + 1;
+    if constexpr (XF) {       // the stage the NEXT step consumes (issued one step ago) while the matrix pipe works
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");
+      xf_stage(rd);
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may outlive the block or race the epilogue
   __builtin_amdgcn_s_barrier();
@@ -921,6 +980,14 @@ template <int BM, int BN, int NST, int NT = 256>
 __global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
   __shared__ __attribute__((aligned(1024))) char smem[NST * (BM + BN) * 128];
   conv_glds_body<BM, BN, NST, NT>(P, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
+}
+
+// The same with the input transform (GemmParams::xf_*); K <= XF_MAX_K input channels.
+#define XF_MAX_K 1024
+template <int BM, int BN, int NT = 256>
+__global__ __launch_bounds__(NT) void conv_glds_xf_kernel(const GemmParams P) {
+  __shared__ __attribute__((aligned(1024))) char smem[3 * (BM + BN) * 128 + 2 * XF_MAX_K * 4];
+  conv_glds_body<BM, BN, 3, NT, true>(P, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
 }
 
 // Job-table form: several convolutions that do not depend on each other (the same-depth layers of an Inception
@@ -1689,6 +1756,8 @@ static void default_epilogue(GemmEpilogue& E) {
 // which: instead of launching, report the kernel the call would take: {kind, bm, bn or tile side, stages} with kind
 // 0 = conv_glds_kernel, 1 = conv_halo_kernel, 2 = conv_halo_s2t_kernel, 3 = conv_halo_d4_kernel
 struct ConvJobOut { void* rec; int* nblocks; int* which; };
+// input transform of the general kernel (GemmParams::xf_*)
+struct ConvXf { const float* save; const float* gamma; const float* beta; int act; };
 
 // Conv2d forward (transposed = 0) or ConvTranspose2d forward / strided-conv data gradient
 // (transposed = 1).  x: NHWC bf16 [nimg][H][W][ldx], channels 0..Cin-1 used.
@@ -1699,7 +1768,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                        float* y2, long long ldy2, const void* mask, long long ldmask, float mask_slope,
                        int stats_post, const BnFinalize* fin, hipStream_t stream, const float* sub = nullptr,
                        long long ld_sub = 0, void* gout = nullptr, long long ld_gout = 0, float gscale = 0.f,
-                       const ConvJobOut* job = nullptr) {
+                       const ConvJobOut* job = nullptr, const ConvXf* xf = nullptr) {
   RIED_CHECK_ARG(x && w && y, "ried_conv2d: null pointer");
   RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
   RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
@@ -1758,6 +1827,12 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                  "ried_conv2d: operand larger than 4 GiB");
   P.A_bytes = (unsigned)a_bytes; P.B_bytes = (unsigned)b_bytes;
   ConvTile t = choose_conv_tile(Cout, npix, phases, conv_ksteps(Cin, kh, kw, sh, sw, transposed), kh * kw);
+  if (xf) {           // only the general kernel transforms its input, with two LDS stages
+    RIED_CHECK_ARG(xf->save && xf->gamma && xf->beta && Cin <= XF_MAX_K && !job && !fin,
+                   "ried_conv2d_xf: bad transform arguments (Cin=%d, at most %d)", Cin, XF_MAX_K);
+    P.xf_save = xf->save; P.xf_gamma = xf->gamma; P.xf_beta = xf->beta; P.xf_act = xf->act;
+    t.nst = 3;
+  }
   int* const which = job ? job->which : nullptr;
   if (job && !which) {
     RIED_CHECK_ARG(!fin && !img_stats && (!stats || P.E.stats_fold),
@@ -1770,7 +1845,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     return RIED_OK;
   }
   // 3x3 stride-1 layers on maps of whole 16x16 tiles: the halo-tile kernel (the input tile serves all nine taps)
-  if (g_forced_tile[0] == 0 && P.E.staged && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 &&
+  if (!xf && g_forced_tile[0] == 0 && P.E.staged && kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 &&
       Cin % 64 == 0 && H % 8 == 0 && W % 8 == 0 && a_bytes < 0xFFFF0000ll - 16384 && b_bytes < 0xFFFFF000ll - 1024 &&
       (nimg % 4 == 0 || (H % 16 == 0 && W % 16 == 0)) && (!img_stats || (H % 16 == 0 && W % 16 == 0))) {
     // 16x16 tiles where the map allows; 8x8 tiles of four images otherwise (64 output channels per block there:
@@ -1792,7 +1867,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     return RIED_OK;
   }
   // data gradients of 3x3 stride-2 layers: all four phases of a tile in one block
-  if (g_forced_tile[0] == 0 && P.E.staged && transposed && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
+  if (!xf && g_forced_tile[0] == 0 && P.E.staged && transposed && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
       Ho == 2 * H && Wo == 2 * W && Cin % 64 == 0 && a_bytes < 0xFFFF0000ll - 16384 && b_bytes < 0xFFFFF000ll - 1024 &&
       H % 16 == 0 && W % 16 == 0) {       // (8x8 maps, four images per block: measured no faster than the general kernel)
     const int ts = 16;
@@ -1807,7 +1882,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     return RIED_OK;
   }
   // ConvTranspose2d(4, 2, 1) forward on maps of whole 16x16 tiles: all four phases of a tile in one block
-  if (g_forced_tile[0] == 0 && P.E.staged && transposed && kh == 4 && kw == 4 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
+  if (!xf && g_forced_tile[0] == 0 && P.E.staged && transposed && kh == 4 && kw == 4 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
       Ho == 2 * H && Wo == 2 * W && Cin % 32 == 0 && H % 16 == 0 && W % 16 == 0 && a_bytes < 0xFFFF0000ll - 16384 &&
       b_bytes < 0xFFFFF000ll - 1024 &&
       // one block per CU: below a block per CU the general kernel's smaller tiles fill the chip better
@@ -1848,6 +1923,19 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     launched = true;                                                                                    \
   }
   bool launched = false;
+  if (xf) {
+#define RIED_XF_CASE(BM_, BN_, NT_)                                                                      \
+    if (t.bm == BM_ && t.bn == BN_) {                                                                    \
+      hipLaunchKernelGGL((conv_glds_xf_kernel<BM_, BN_, NT_>), grid, dim3(NT_), 0, stream, P);            \
+      launched = true;                                                                                   \
+    }
+    RIED_XF_CASE(128, 256, 512) RIED_XF_CASE(64, 256, 512) RIED_XF_CASE(128, 128, 256) RIED_XF_CASE(128, 64, 256)
+    RIED_XF_CASE(64, 128, 256) RIED_XF_CASE(64, 64, 256) RIED_XF_CASE(32, 128, 256) RIED_XF_CASE(32, 64, 256)
+#undef RIED_XF_CASE
+    RIED_CHECK_ARG(launched, "ried_conv2d_xf: no kernel for tile %dx%d", t.bm, t.bn);
+    RIED_CHECK_LAUNCH("ried_conv2d_xf");
+    return RIED_OK;
+  }
   RIED_CONV_CASE8(128, 256, 2) RIED_CONV_CASE8(128, 256, 3) RIED_CONV_CASE8(64, 256, 2) RIED_CONV_CASE8(64, 256, 3)
   RIED_CONV_CASE(128, 128, 2) RIED_CONV_CASE(128, 128, 3) RIED_CONV_CASE(128, 64, 2) RIED_CONV_CASE(128, 64, 3)
   RIED_CONV_CASE(128, 64, 4) RIED_CONV_CASE(64, 128, 2) RIED_CONV_CASE(64, 128, 3) RIED_CONV_CASE(64, 128, 4)
@@ -1867,6 +1955,21 @@ extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y,
                            int stats_post, hipStream_t stream) {
   return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, bias, act,
                      stats, accumulate, out_f32, y2, ldy2, mask, ldmask, mask_slope, stats_post, nullptr, stream);
+}
+
+// ried_conv2d whose input x is the RAW convolution output of a BasicConv2d layer (src/rinet.py:183-205): the kernel
+// applies that layer's train-mode BatchNorm (xf_save = [2][Cin] mean, 1/sqrt(var + eps); xf_gamma, xf_beta) and its
+// activation (xf_act: 0 none, 1 ReLU) to the operand on its way through LDS, so that the normalised tensor is never
+// written or read - one pass over every activation less.  Always the general kernel (Cin <= 1024).
+extern "C" int ried_conv2d_xf(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
+                              int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                              int transposed, const float* bias, int act, float* stats, int accumulate, int stats_post,
+                              const float* xf_save, const float* xf_gamma, const float* xf_beta, int xf_act,
+                              hipStream_t stream) {
+  ConvXf xf{xf_save, xf_gamma, xf_beta, xf_act};
+  return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, bias, act,
+                     stats, accumulate, 0, nullptr, 0, nullptr, 0, 0.f, stats_post, nullptr, stream, nullptr, 0,
+                     nullptr, 0, 0.f, nullptr, &xf);
 }
 
 // Job-table form of ried_conv2d: convolutions that do not depend on each other in one launch of the general kernel

@@ -386,6 +386,7 @@ class ConvCore:
         (Cout, Cin, 1, 1); the packed copies replicate it over the taps and the weight gradient sums the taps' slabs
         (times 1/9).  No pooled tensor is written or read, forward or backward."""
         self.ctx, self.wname = ctx, wname
+        self.xf_src: Optional["ConvBN"] = None      # set by ConvBN: the layer whose raw output this conv normalises itself
         self.pool_fold = pool_fold
         if pool_fold:
             assert _pair(k) == (3, 3) and _pair(stride) == (1, 1) and _pair(pad) == (1, 1) and not deconv
@@ -444,6 +445,12 @@ class ConvCore:
                     ctx.add_pack(w, self.wpt, cin, kh, kw, cout, t, kw, 1, cin * t, sigma)
 
     def conv(self, y: View, x: Optional[View] = None, **kw):
+        src = self.xf_src
+        if src is not None and x is None:    # the producer stopped at its statistics: normalise its raw output on the fly
+            st = self.ctx.st
+            ops.conv2d_xf(src.raw, self.wp, y, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, src.save,
+                          st.p[src.bn + ".weight"], st.p[src.bn + ".bias"], src.act, transposed=self.deconv, **kw)
+            return
         ops.conv2d(self.xin.v if x is None else x, self.wp, y, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw,
                    transposed=self.deconv, **kw)
 
@@ -487,12 +494,14 @@ class ConvBN:
 
     def __init__(self, ctx: Ctx, prefix: str, cin, cout, k, stride, pad, xin: Slot, out: Slot, deconv=False,
                  accumulate=False, need_dx=True, conv_key=None, bn_key=None, bias=False, act=1, shared=False,
-                 wgrad_out: Optional[torch.Tensor] = None, defer_apply=False, pool_fold=False):
+                 wgrad_out: Optional[torch.Tensor] = None, defer_apply=False, pool_fold=False,
+                 xf_src: Optional["ConvBN"] = None):
         """bias / act / shared / wgrad_out serve the legacy networks (src/networks.py:466-542): a conv bias in front
         of the BatchNorm (train mode: it only shifts running_mean), the activation code of ops.bn_apply, layers
         applied several times per forward (BatchNorm and bias gradients then add onto the state's), and a
         private buffer for this use's weight gradient.  defer_apply (forward-only plans): the layer stops at the
-        statistics (`save`); its consumer reads `raw` and applies the normalisation itself."""
+        statistics (`save`); its consumer reads `raw` and applies the normalisation itself - xf_src names that
+        producer to the consumer, whose convolution then normalises its operand on the way through LDS."""
         self.ctx, self.prefix, self.lane = ctx, prefix, ctx.build_lane
         conv_key = conv_key or (prefix + (".deconv" if deconv else ".conv"))
         self.bn = bn_key or (prefix + ".bn")
@@ -500,11 +509,13 @@ class ConvBN:
         self.act, self.shared = act, shared
         grp = ctx.dx_group
         grouped = grp is not None and ctx.grads and need_dx and grp.wants(xin, k, stride, pad)
-        fwd_member = (grp is not None and not ctx.grads and not defer_apply and not bias
+        fwd_member = (grp is not None and not ctx.grads and not bias
                       and grp.wants(xin, k, stride, pad))      # forward-only plans: the group shares the convolution
         self.core = ConvCore(ctx, conv_key + ".weight", cin, cout, k, stride, pad, deconv, xin,
                              need_dx and not grouped, wgrad_out=wgrad_out, pool_fold=pool_fold)
         c = self.core
+        c.xf_src = xf_src
+        assert xf_src is None or (not ctx.grads and xf_src.defer_apply and xf_src.core.cout == cin)
         assert out.shape == (c.N, c.Ho, c.Wo, cout), (prefix, out.shape, (c.N, c.Ho, c.Wo, cout))
         self.out, self.accumulate = out, accumulate
         self.raw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
@@ -730,7 +741,7 @@ class InputGradGroup:
                 ctx.add_pack(ctx.st.p[m.core.wname], self.wcat[c0:], cin, 1, 1, co, rs, 1, 1, cs, dst_pitch=total)
             c0 += co
         self.fwd = (ctx.st is not None and ctx.training and len(self.members) >= 2 and
-                    not any(m.bias_key or m.defer_apply for m in self.members))
+                    not any(m.bias_key for m in self.members))
         self.images = self.fwd and ctx.per_image          # one statistics row per image
         self.folded = self.fwd and not self.images and all(m.sliced for m in self.members)
         self.fwd_jobs = None
@@ -1131,7 +1142,7 @@ class Identity:
 
 def _chain(ctx: Ctx, seq: Seq, prefix: str, specs, xin: Slot, out: Slot, deconv=False, accumulate=False):
     """specs: [(name, cin, cout, k, stride, pad)]; the last layer writes `out`, inner layers get own buffers."""
-    cur = xin
+    cur, prev = xin, None
     for i, (name, cin, cout, k, s, p) in enumerate(specs):
         last = i == len(specs) - 1
         N, H, W, _ = cur.shape
@@ -1141,10 +1152,38 @@ def _chain(ctx: Ctx, seq: Seq, prefix: str, specs, xin: Slot, out: Slot, deconv=
         else:
             Ho, Wo = _conv_out(H, kh, sh, ph), _conv_out(W, kw, sw, pw)
         dst = out if last else Slot(ctx.act(N, Ho, Wo, cout))
-        seq.add(ConvBN(ctx, prefix + "." + name, cin, cout, k, s, p, cur, dst, deconv=deconv,
-                       accumulate=accumulate and last))
+        # forward-only plans: an inner layer whose one consumer runs the general convolution kernel stops at its
+        # statistics, and the consumer normalises the raw output itself (no second pass over the tensor)
+        defer = not last and _xf_consumer_ok(ctx, specs[i + 1], deconv, Ho, Wo)
+        prev = seq.add(ConvBN(ctx, prefix + "." + name, cin, cout, k, s, p, cur, dst, deconv=deconv,
+                              accumulate=accumulate and last, defer_apply=defer,
+                              xf_src=prev if (prev is not None and prev.defer_apply) else None))
         cur = dst
     return cur
+
+
+# Off unless RIED_XF_FUSE=1.  Measured on 32 slices of 512 x 512: the consumers' launches get 40-45 us slower each
+# (the normalisation is as much vector work per stage as the stage's matrix products: 62 -> 108 us with the
+# transform between the DMA wait and the barrier, no better one stage ahead of the products on three LDS stages)
+# while the apply pass they replace took 37 us: 5.29 -> 5.89 ms per batch.
+XF_FUSE = bool(os.environ.get("RIED_XF_FUSE"))
+
+
+def _xf_consumer_ok(ctx: Ctx, spec, deconv: bool, H: int, W: int) -> bool:
+    """Will the layer `spec` (input H x W) take the general convolution kernel - the one that can normalise its
+    operand on the fly (ops.conv2d_xf)?  Mirrors the dispatch of ried_conv2d: 3x3 stride-1 layers on maps of whole
+    tiles and ConvTranspose2d(4, 2, 1) on 16 x 16 tiles have kernels of their own."""
+    if not XF_FUSE or ctx.grads or not ctx.training or ctx.per_image or ctx.st is None:
+        return False
+    _, cin, cout, k, s, p = spec
+    (kh, kw), (sh, sw) = _pair(k), _pair(s)
+    if cin > 1024:
+        return False
+    if not deconv and (kh, kw, sh, sw) == (3, 3, 1, 1) and cin % 64 == 0 and H % 8 == 0 and W % 8 == 0:
+        return False
+    if deconv and (kh, kw, sh, sw) == (4, 4, 2, 2) and cin % 32 == 0 and H % 16 == 0 and W % 16 == 0:
+        return False
+    return True
 
 
 def _pool_branch(ctx, seq, prefix, xin: Slot, out_slice: Slot, cin, cout):

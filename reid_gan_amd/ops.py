@@ -79,6 +79,15 @@ def conv2d(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed
                     _stream())
 
 
+def conv2d_xf(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, xf_save, xf_gamma, xf_beta, xf_act=1,
+              transposed=False, bias=None, act=0, stats=None, accumulate=False, stats_post=False):
+    """conv2d on act(batchnorm(x)) with x the raw convolution output of the producing layer (save = its mean /
+    invstd): the normalised tensor is formed inside the kernel, never stored."""
+    lib.ried_conv2d_xf(x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C, kh, kw, sh, sw, ph, pw,
+                       int(transposed), _p(bias), act, _p(stats), int(accumulate), int(stats_post), _p(xf_save),
+                       _p(xf_gamma), _p(xf_beta), int(xf_act), _stream())
+
+
 def conv2d_which(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed=False, bias=None, act=0,
                  stats=None, accumulate=False, out_f32=False, y2: Optional[torch.Tensor] = None,
                  mask: Optional[View] = None, mask_slope=0.0, stats_post=False) -> str:

@@ -1035,3 +1035,49 @@ def test_fused_attention_forward_backward(n, d, C):
     ops.attn_bwd(qv.images(1, 3), dq.images(1, 3), dv.images(1, 3), Ov.images(1, 3), lse.data_ptr() + 4 * n, gd, None, d)
     got2 = dq.torch().float().cpu().reshape(N, n, -1)
     assert torch.isnan(got2[0]).all() and torch.equal(got2[1:], got[1:])
+
+
+XF_CASES = [  # cin, cout, k, stride, pad, H, N, transposed
+    (64, 64, (1, 7), 1, (0, 3), 16, 4, False),      # padding along W: transformed zeros must stay zero
+    (48, 96, (7, 1), 1, (3, 0), 8, 8, False),       # channels per tap not a multiple of the 64-wide stage
+    (128, 128, (3, 3), 2, (1, 1), 16, 4, False),    # the grid blocks' strided last layers
+    (256, 32, (1, 1), 1, (0, 0), 8, 4, False),      # 32-row tile
+    (64, 256, (1, 7), 1, (0, 3), 64, 8, False),     # 256-pixel tile on eight waves
+    (224, 192, (3, 3), 1, (1, 1), 4, 8, False),     # a 3x3 layer forced onto the general kernel
+    (128, 64, (4, 4), 2, (1, 1), 8, 4, True),       # transposed: four phases
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,H,N,tr", XF_CASES)
+def test_conv2d_with_batchnorm_input_transform(cin, cout, k, s, p, H, N, tr):
+    """ried_conv2d_xf: the operand is a raw convolution output; BatchNorm (given mean / invstd) + ReLU are applied
+    inside the kernel.  Against torch on the explicitly normalised tensor (rounded to bf16, as the kernel rounds what
+    it feeds the matrix cores), with statistics of the result in the folded form."""
+    x = r(N, cin, H, H, seed=70) * 2 + 0.3
+    mean, invstd = r(cin, seed=71) * 0.5, r(cin, seed=72).abs() + 0.5
+    gamma, beta = r(cin, seed=73) + 1.0, r(cin, seed=74) * 0.3
+    xn = F.relu((x - mean[None, :, None, None]) * (gamma * invstd)[None, :, None, None] + beta[None, :, None, None])
+    xn = xn.to(torch.bfloat16).float()
+    if tr:
+        w = r(cin, cout, *k, seed=75, scale=(cin * k[0] * k[1]) ** -0.5)
+        ref = F.conv_transpose2d(xn, w, None, s, p)
+        wp = pack(w.permute(1, 0, 2, 3))
+    else:
+        w = r(cout, cin, *k, seed=75, scale=(cin * k[0] * k[1]) ** -0.5)
+        ref = F.conv2d(xn, w, None, s, p)
+        wp = pack(w)
+    Ho, Wo = ref.shape[-2:]
+    yv = ops.new_view(N, Ho, Wo, cout)
+    save = torch.stack([mean, invstd]).contiguous().to(DEV)
+    stats = torch.zeros(ops.bn_fold_rows(), 2, cout, device=DEV)
+    ops.conv2d_xf(to_view(x), wp, yv, k[0], k[1], s, s, p[0], p[1], save, gamma.to(DEV), beta.to(DEV), 1,
+                  transposed=tr, stats=stats, stats_post=2)
+    close(from_view(yv), ref, what="y")
+    st = stats.sum(0)
+    close(st[1].cpu(), (ref * ref).sum((0, 2, 3)), 5e-3, "sum of squares")
+    # no activation: the affine map alone
+    xa = ((x - mean[None, :, None, None]) * (gamma * invstd)[None, :, None, None] + beta[None, :, None, None])
+    xa = xa.to(torch.bfloat16).float()
+    ref2 = F.conv_transpose2d(xa, w, None, s, p) if tr else F.conv2d(xa, w, None, s, p)
+    ops.conv2d_xf(to_view(x), wp, yv, k[0], k[1], s, s, p[0], p[1], save, gamma.to(DEV), beta.to(DEV), 0, transposed=tr)
+    close(from_view(yv), ref2, what="y (no activation)")
