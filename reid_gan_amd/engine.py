@@ -132,6 +132,7 @@ class Ctx:
         self.build_lane = 0                # lane (stream + scratch set) the layers being built will run on
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
         self.nine: Optional[torch.Tensor] = None      # device scalar 9.0 (divisor of the pool-folded weights)
+        self.splitk_target, self.splitk_minpix = 0, 0      # 0: the defaults of _splitk (a launch per layer)
         self.sn = ops.SnJobs()             # every spectral-norm layer: power iteration / sigma gradient per launch
         # Deferred weight gradients (one launch per tile shape) and the reduction of their split-K slabs (one launch),
         # issued by end_backward().  One pair of tables per gradient bucket: with data parallelism a network's
@@ -360,9 +361,9 @@ class Slot:
         return (self.n1 - self.n0, v.H, v.W, self.C)
 
 
-def _splitk(blocks: int, kpix: int, target: int = 0) -> int:
+def _splitk(blocks: int, kpix: int, target: int = 0, minpix: int = 0) -> int:
     target = target or int(os.environ.get("RIED_SPLITK_TARGET", "384"))
-    minpix = int(os.environ.get("RIED_SPLITK_MINPIX", "768"))       # measured: 256 -> 768 pixels per split, -1 % per step
+    minpix = minpix or int(os.environ.get("RIED_SPLITK_MINPIX", "768"))       # measured: 256 -> 768 pixels per split, -1 % per step
     s = max(1, min((target + blocks - 1) // blocks, (kpix + minpix - 1) // minpix))
     return min(s, 512)
 
@@ -414,7 +415,7 @@ class ConvCore:
             # weight gradient: gathered tensor g / pixel-indexed tensor p (see ried_conv2d_wgrad)
             cg, cp = (cout, cin) if deconv else (cin, cout)
             kp = N * (H * W if deconv else self.Ho * self.Wo)
-            self.splitk = _splitk(ops.conv2d_wgrad_tiles(cg, cp) * taps, kp)
+            self.splitk = _splitk(ops.conv2d_wgrad_tiles(cg, cp) * taps, kp, ctx.splitk_target, ctx.splitk_minpix)
             self.slab_off = ctx.alloc_slab(self.splitk * taps * cin * cout)
             out = ctx.st.g[wname] if wgrad_out is None else wgrad_out
             if pool_fold: # slab [splitk][9][Cp=cout][Cg=cin]: (split, tap) is one reduction axis -> master (Cout,Cin,1,1)
@@ -1353,6 +1354,10 @@ class Generator:
         assert H % 16 == 0 and W % 16 == 0, "RIGAN needs H, W divisible by 16 (skip connections must line up)"
         self.st = state
         self.ctx = ctx = Ctx(state, device, grads, training)
+        # every weight gradient of this network runs in the grouped launches: the grid is shared by all layers, so a
+        # layer needs far fewer blocks of its own (fewer split-K slabs to write and reduce) than a launch per layer
+        ctx.splitk_target = int(os.environ.get("RIED_SPLITK_TARGET_G", "0"))
+        ctx.splitk_minpix = int(os.environ.get("RIED_SPLITK_MINPIX_G", "0"))
         if per_image_stats:
             if grads or not training or H % 256 or W % 256:
                 raise ValueError("per-image statistics: forward-only train-mode plans on H, W divisible by 256")

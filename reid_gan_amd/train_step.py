@@ -96,6 +96,8 @@ class TrainStep:
         # two contend for the CUs and the step gets 0.12 ms slower, so it is off unless asked for.
         self.overlap_dreal = bool(os.environ.get("RIED_OVERLAP_DREAL"))
         self._d_side = None
+        self.overlap_dprep = not os.environ.get("RIED_NO_OVERLAP_DPREP")
+        self._d_prepared = False
         self.graphs = None          # [(graph, tensor to all-reduce after it or None)]
         self.steps_done = 0
         self.segment = -1
@@ -161,7 +163,9 @@ class TrainStep:
 
     def _d_iteration(self, last: bool):
         B, sc, D = self.B, self.sc, self.D
-        if last or self._d_side is None:
+        if not last and self._d_side is None and self._d_prepared:
+            out = D.forward_images(self.d_in, 0, 2 * B)      # spectral norms and repacks ran beside the generator forward
+        elif last or self._d_side is None:
             out = D.forward(self.d_in)
         else:          # the target half has been running beside the generator forward (see _body)
             out = D.forward_images(self.d_in, B, 2 * B)
@@ -231,7 +235,12 @@ class TrainStep:
     def _body(self):
         B = self.B
         self._vgg_side = self._fork(VGG_LANE, self.overlap_vgg)      # target features beside the generator forward
+        # ... and so do the first discriminator iteration's spectral norms and weight repacks (small kernels that need
+        # only D's weights): 0.1 ms off the critical path
+        self._d_prepared = self.overlap_vgg and self.overlap_dprep
         with torch.cuda.stream(self._vgg_side):
+            if self._d_prepared:
+                self.D.prepare()
             self.V.forward(self.y, B, 2 * B, src0=0)
         # The first discriminator iteration's weight preparation (spectral norms, packing) and its forward pass on
         # the TARGET images need nothing the generator computes: they run beside the generator forward too, whose
@@ -243,7 +252,9 @@ class TrainStep:
                 self.D.prepare()
                 self.D.forward_images(self.d_in, 0, B)
         pred = self.G.forward(self.x)
-        if self.segmented:           # a side stream may not stay open across a collective (graph segment boundary)
+        # (a side stream may not stay open across a collective = graph segment boundary; and the discriminator
+        # forward that comes next reads the weights repacked on it)
+        if self.segmented or self._d_prepared:
             self._join(self._vgg_side)
             self._vgg_side = None
         assert pred.data_ptr() == self.d_in[B:].data_ptr()
