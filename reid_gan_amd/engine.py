@@ -997,7 +997,7 @@ class Par:
     def _build_levels(self):
         dev = self.ctx.device
         depth = max(len(b.layers) for b in self.branches)
-        levels, worth = [], False
+        levels, worth, carry = [], False, []
         for k in range(depth):
             items = [b.layers[k] for b in self.branches if k < len(b.layers)]
             ok = [l for l in items if isinstance(l, ConvBN) and l.level_ok()]
@@ -1015,8 +1015,13 @@ class Par:
             else:
                 lv["fwd_conv"] = None
                 lv["fwd_conv_single"] = convs
-            lv["fwd_bn"], lv["fwd_bn_single"] = self._bn_tables(
-                [(l, l.fwd_bn_job()) for l in ok if not l.bn_fwd_grouped], dev)
+            # (the first layers' BatchNorms that add onto the block output - after the identity path has written it,
+            # which happened before this Par - ride in the next level's table instead of a launch of their own)
+            pairs = carry + [(l, l.fwd_bn_job()) for l in ok if not l.bn_fwd_grouped]
+            carry = []
+            if k == 0 and depth > 1 and pairs and all(l.accumulate for l, _ in pairs):
+                carry, pairs = pairs, []
+            lv["fwd_bn"], lv["fwd_bn_single"] = self._bn_tables(pairs, dev)
             # backward: BatchNorms, then data gradients (level 0: the branches' inputs are one tensor - one by one)
             lv["bwd_bn"], lv["bwd_bn_single"] = self._bn_tables(
                 [(l, l.bwd_bn_job()) for l in ok if not l.bn_bwd_grouped], dev)
