@@ -1,16 +1,19 @@
 """Timeline of the LAST training step in a rocprofv3 kernel trace of tools/step_prof.py (graph replays).
-usage: step_timeline.py <trace dir> [bucket_us=100]
-A step ends with the generator's Adam launch (the third adam_kernel of the step).  Prints, per time bucket, how much
+usage: step_timeline.py <trace dir> [bucket_us=100] [marker=adam_kernel] [markers per repetition=3]
+A step ends with the generator's Adam launch (the third adam_kernel of the step); for the inference batch of
+tools/infer_prof.py the marker is ssim_fwd_kernel, once per repetition.  Prints, per time bucket, how much
 of it had 0 / 1 / 2+ kernels running and which kernels took the most time in it; then the totals."""
 import csv, glob, sys, collections
 d = sys.argv[1]
 bucket = float(sys.argv[2]) if len(sys.argv) > 2 else 100.0
 rows = list(csv.DictReader(open(glob.glob(d + "/**/*kernel_trace.csv", recursive=True)[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-adam = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("adam_kernel")]
-lo, hi = adam[-4] + 1, adam[-1] + 1
+marker = sys.argv[3] if len(sys.argv) > 3 else "adam_kernel"
+per = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+adam = [i for i, r in enumerate(rows) if marker in r["Kernel_Name"]]
+lo, hi = adam[-per - 1] + 1, adam[-1] + 1
 seq = rows[lo:hi]
-t0 = int(rows[adam[-4]]["End_Timestamp"])
+t0 = int(rows[adam[-per - 1]]["End_Timestamp"])
 ev = []
 for r in seq:
     s, e = (int(r["Start_Timestamp"]) - t0) / 1e3, (int(r["End_Timestamp"]) - t0) / 1e3
