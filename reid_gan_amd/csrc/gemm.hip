@@ -1371,7 +1371,11 @@ __device__ constexpr D4Step D4_STEPS[16] = {
 
 template <int BM>
 __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P) {
-  constexpr int TS = 16, BN = 256, WN = 4, NSTEP = 16;
+  // BM = 32: a weight stage (64 rows) holds the taps of TWO consecutive products, rows 0-31 and 32-63, and a step runs
+  // both between one pair of barriers: 16 MFMAs per wave and barrier instead of 8 (the layer with 32 output channels
+  // was bound by its barriers), eight steps per slab.
+  constexpr int PAIR = BM == 32 ? 2 : 1;
+  constexpr int TS = 16, BN = 256, WN = 4, NSTEP = 16 / PAIR;
   constexpr int TWP = TS + 2, HR = TWP * TWP;              // 324 input pixels per block
   constexpr int NLB = (HR * 8 + 511) / 512;                // 6
   constexpr int BBUF = NLB * 512 * 16;
@@ -1407,8 +1411,10 @@ __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P
 #pragma unroll
   for (int i = 0; i < NLA; ++i) {
     const int ci = i * 512 + tid, m = ci >> 3, q = (ci & 7) ^ (m & 7);
-    aoff[i] = m0 + m < P.M ? (unsigned)(m0 + m) * (unsigned)P.A.ld * 2u + (unsigned)q * 16u : A_OOB;
+    const int mr = PAIR == 2 ? (m & 31) : m;               // (paired stages: rows 32-63 are the second tap's rows 0-31)
+    aoff[i] = m0 + mr < P.M ? (unsigned)(m0 + mr) * (unsigned)P.A.ld * 2u + (unsigned)q * 16u : A_OOB;
   }
+  const bool second_tap = PAIR == 2 && ((tid >> 3) & 32);  // this lane's weight row belongs to the step's second tap
 #pragma unroll
   for (int i = 0; i < NLB; ++i) {
     const int ci = i * 512 + tid, hr = ci >> 3, q = (ci & 7) ^ (hr & 7);
@@ -1422,7 +1428,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P
   auto issueA = [&](int slab, int step, int stage) {
     unsigned dead = slab < nsl ? 0u : A_OOB;
     asm volatile("" : "+v"(dead));
-    const unsigned wk = (unsigned)(D4_STEPS[step].wtap * P.K + slab * 64) * 2u;
+    unsigned wk = (unsigned)(D4_STEPS[step * PAIR].wtap * P.K + slab * 64) * 2u;
+    if (PAIR == 2 && second_tap) wk = (unsigned)(D4_STEPS[step * PAIR + PAIR - 1].wtap * P.K + slab * 64) * 2u;
 #pragma unroll
     for (int i = 0; i < NLA; ++i) glds16(rsA, (aoff[i] + wk) | dead, dA + stage * ABUF + i * 8192);
   };
@@ -1450,8 +1457,8 @@ __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P
     hr0[j] = (p / TS + 1) * TWP + (p % TS) + 1;
   }
   bf16x8_t fa[2][TM], fb[2][TN];
-  auto load_frags = [&](int stage, int bbuf, int toff, int ks, bool new_pixels) {
-    const char* sa = sA + stage * ABUF + wm * (BM / 2) * 128 + frow;
+  auto load_frags = [&](int stage, int sub, int bbuf, int toff, int ks, bool new_pixels) {
+    const char* sa = sA + stage * ABUF + (sub * 32 + wm * (BM / 2)) * 128 + frow;
     const char* sb = sB + bbuf * BBUF;
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + (ks ? sw1 : sw0));
@@ -1486,26 +1493,32 @@ __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P
       else if (n_after == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      const int toff = D4_STEPS[step].shift_i * TWP + D4_STEPS[step].shift_j;
-      const int ph = D4_STEPS[step].phase;
-      const bool newp = step == 0 || D4_STEPS[step].shift_i != D4_STEPS[step - (step ? 1 : 0)].shift_i ||
-                        D4_STEPS[step].shift_j != D4_STEPS[step - (step ? 1 : 0)].shift_j;
-      load_frags(step % NSA, slab & 1, toff, 0, newp);
-      if (step < NSTEP - 3) issueA(slab, step + 3, (step + 3) % NSA);
-      else issueA(slab + 1, step + 3 - NSTEP, (step + 3) % NSA);
-      if (step < NLB) issueB(slab + 1, step);
-      if (both) load_frags(step % NSA, slab & 1, toff, 1, newp);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[ph][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[ph][i][j], 0, 0, 0);
-      if (both) {
+      for (int sub = 0; sub < PAIR; ++sub) {
+        const int t = step * PAIR + sub;                       // index into the sixteen (phase, tap) products
+        const int toff = D4_STEPS[t].shift_i * TWP + D4_STEPS[t].shift_j;
+        const int ph = D4_STEPS[t].phase;
+        const bool newp = t == 0 || D4_STEPS[t].shift_i != D4_STEPS[t - (t ? 1 : 0)].shift_i ||
+                          D4_STEPS[t].shift_j != D4_STEPS[t - (t ? 1 : 0)].shift_j;
+        load_frags(step % NSA, sub, slab & 1, toff, 0, newp);
+        if (sub == 0) {
+          if (step < NSTEP - 3) issueA(slab, step + 3, (step + 3) % NSA);
+          else issueA(slab + 1, step + 3 - NSTEP, (step + 3) % NSA);
+          if (step < NLB) issueB(slab + 1, step);
+        }
+        if (both) load_frags(step % NSA, sub, slab & 1, toff, 1, newp);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[ph][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[ph][i][j], 0, 0, 0);
+            acc[ph][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[0][i], fb[0][j], acc[ph][i][j], 0, 0, 0);
+        if (both) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[ph][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[1][i], fb[1][j], acc[ph][i][j], 0, 0, 0);
+        }
       }
     }
   }
