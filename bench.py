@@ -460,8 +460,11 @@ def main():
     x, y = synth_batch(args.batch, args.size, seed=1234 + rank)
     ts.x.copy_(x.cuda())
     ts.y.copy_(y.cuda())
-    for _ in range(args.warmup):
+    first = None
+    for i in range(args.warmup):
         ts.step()
+        if i == 0:        # the timed loop replays one batch, which the discriminator soon separates perfectly (its
+            first = ts.losses()      # hinge losses then read 0): the first step's values are the sanity signal
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -487,7 +490,7 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: full RIED-GAN training step, batch {args.batch} of "
                                f"1x{args.size}x{args.size} patches per GPU, bf16 storage / fp32 accumulate",
                    "global_batch": world * args.batch, "patch": args.size, "parallelism": f"dp{world}",
-                   "hip_graph": not args.no_graph, "losses": losses},
+                   "hip_graph": not args.no_graph, "losses": losses, "losses_first_step": first},
     }
     if args.size == 64:
         out["step_mfma_frac"] = value / world * FLOP_PER_PATCH_64 / PEAK_MFMA_BF16
