@@ -86,22 +86,18 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
   // float atomics of the 256 tiles of a 512 x 512 image all land on one cache line and serialise - that, not the
   // filter, was what bounded the kernel on full slices.
   float s_ssim_a = 0.f, s_mse_a = 0.f, s_ssim_b = 0.f, s_mse_b = 0.f;
-  for (int tile = blockIdx.x * tpb; tile < min(ntiles, (blockIdx.x + 1) * tpb); ++tile) {
-  const int tx = tile % tiles_x, ty = tile / tiles_x;
-  const int x0 = tx * TS - HALO, y0 = ty * TS - HALO;
-  if (tile != blockIdx.x * tpb) __syncthreads();        // the previous tile's LDS planes have been read
-  float cs[NIMG];                                       // shift constants: the tile's first pixel (always inside)
+  // The halo tile of the NEXT tile is fetched into registers while the current one is filtered (the loads of a tile
+  // are ~2 us of latency, as long as its whole filter): raw values and the tile's shift constants travel together.
+  constexpr int NL = (TIN * TIN + 255) / 256;
+  float pv[NL][NIMG], pcs[NIMG];
+  unsigned pok = 0;
+  const int tile_end = min(ntiles, (blockIdx.x + 1) * tpb);
+  auto fetch = [&](int tile) {
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int x0 = tx * TS - HALO, y0 = ty * TS - HALO;
 #pragma unroll
-  for (int k = 0; k < NIMG; ++k) {
-    float t = imgs[k][ibase + (long long)(ty * TS) * W + tx * TS];
-    cs[k] = do_clamp ? clampf(t, lo, hi) : t;
-  }
-
-  {
-    // every global load of the halo tile is issued before the first LDS store, so that the block pays the
-    // memory latency once instead of once per pass of the loop
-    constexpr int NL = (TIN * TIN + 255) / 256;
-    float v[NL][NIMG];
+    for (int k = 0; k < NIMG; ++k) pcs[k] = imgs[k][ibase + (long long)(ty * TS) * W + tx * TS];
+    pok = 0;
 #pragma unroll
     for (int j = 0; j < NL; ++j) {
       int i = threadIdx.x + 256 * j;
@@ -109,23 +105,33 @@ __global__ __launch_bounds__(256) void ssim_fwd_kernel(const float* __restrict__
       int gy = y0 + yy, gx = x0 + xx;
       bool ok = i < TIN * TIN && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W;
       long long off = ok ? ibase + (long long)gy * W + gx : ibase;
+      pok |= (ok ? 1u : 0u) << j;
+#pragma unroll
+      for (int k = 0; k < NIMG; ++k) pv[j][k] = imgs[k][off];
+    }
+  };
+  if (blockIdx.x * tpb < tile_end) fetch(blockIdx.x * tpb);
+  for (int tile = blockIdx.x * tpb; tile < tile_end; ++tile) {
+  const int tx = tile % tiles_x, ty = tile / tiles_x;
+  if (tile != blockIdx.x * tpb) __syncthreads();        // the previous tile's LDS planes have been read
+  float cs[NIMG];                                       // shift constants: the tile's first pixel (always inside)
+#pragma unroll
+  for (int k = 0; k < NIMG; ++k) cs[k] = do_clamp ? clampf(pcs[k], lo, hi) : pcs[k];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    int i = threadIdx.x + 256 * j;
+    if (i < TIN * TIN) {
+      int yy = i / TIN, xx = i - yy * TIN;
+      const bool ok = (pok >> j) & 1u;
 #pragma unroll
       for (int k = 0; k < NIMG; ++k) {
-        float t = imgs[k][off];
+        float t = pv[j][k];
         if (do_clamp) t = clampf(t, lo, hi);
-        v[j][k] = (ok ? t : 0.f) - cs[k];       // zero padding, then the shift
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      int i = threadIdx.x + 256 * j;
-      if (i < TIN * TIN) {
-        int yy = i / TIN, xx = i - yy * TIN;
-#pragma unroll
-        for (int k = 0; k < NIMG; ++k) tin[k * TPL + yy * TP + xx] = v[j][k];
+        tin[k * TPL + yy * TP + xx] = (ok ? t : 0.f) - cs[k];       // zero padding, then the shift
       }
     }
   }
+  if (tile + 1 < tile_end) fetch(tile + 1);             // in flight during the two filter passes below
   __syncthreads();
   // Horizontal pass, TIN rows x TS columns: a thread owns 8 consecutive outputs of one row and slides over their
   // 18 inputs, so that every input (and its products) is read and formed once instead of once per tap.  Lanes
