@@ -1169,9 +1169,11 @@ def _chain(ctx: Ctx, seq: Seq, prefix: str, specs, xin: Slot, out: Slot, deconv=
 
 
 # Off unless RIED_XF_FUSE=1.  Measured on 32 slices of 512 x 512: the consumers' launches get 40-45 us slower each
-# (the normalisation is as much vector work per stage as the stage's matrix products: 62 -> 108 us with the
-# transform between the DMA wait and the barrier, no better one stage ahead of the products on three LDS stages)
-# while the apply pass they replace took 37 us: 5.29 -> 5.89 ms per batch.
+# (62 -> 108 us, with the transform between the DMA wait and the barrier or one stage ahead of the products on
+# three LDS stages) while the apply pass they replace took 37 us: 5.29 -> 5.89 ms per batch.  The cause is LDS
+# bandwidth: per stage a 64 x 256 block already moves 136 KB through LDS (DMA writes + fragment reads, ~1060 clocks
+# against ~1020 of matrix work), and reading and rewriting the pixel operand in place adds 128 KB.  A form that pays
+# would normalise on the way IN (global -> registers -> LDS: no extra LDS traffic), at the price of the LDS-DMA path.
 XF_FUSE = bool(os.environ.get("RIED_XF_FUSE"))
 
 
