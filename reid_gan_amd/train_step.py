@@ -237,7 +237,8 @@ class TrainStep:
         self._vgg_side = self._fork(VGG_LANE, self.overlap_vgg)      # target features beside the generator forward
         # ... and so do the first discriminator iteration's spectral norms and weight repacks (small kernels that need
         # only D's weights): 0.1 ms off the critical path
-        self._d_prepared = self.overlap_vgg and self.overlap_dprep
+        dreal = self.overlap_dreal and self.D.splittable      # (then the preparation runs with that pass, once)
+        self._d_prepared = self.overlap_vgg and self.overlap_dprep and not dreal
         with torch.cuda.stream(self._vgg_side):
             if self._d_prepared:
                 self.D.prepare()
@@ -246,7 +247,7 @@ class TrainStep:
         # the TARGET images need nothing the generator computes: they run beside the generator forward too, whose
         # small dependent kernels leave most of the chip idle.
         self._d_side = None
-        if self.overlap_dreal and self.D.splittable:
+        if dreal:
             self._d_side = self._fork(DBWD_LANE)
             with torch.cuda.stream(self._d_side):
                 self.D.prepare()

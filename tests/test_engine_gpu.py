@@ -595,3 +595,92 @@ def test_inference_at_the_benchmark_size_with_and_without_sibling_groups(monkeyp
     for i in range(B):
         for u, v in zip(ma[i][1], mb[i][1]):
             assert abs(u - v) <= 5e-3 * abs(v) + 1e-5, (i, ma[i], mb[i])
+
+
+def test_optional_step_overlaps_give_the_same_step(monkeypatch):
+    """The switchable parts of the captured step - the discriminator's weight preparation beside the generator
+    forward (on by default) and its pass over the target half there too (off by default: measured slower) - change
+    the order of launches, not the arithmetic: same losses and weights as the step without them."""
+    B, H = 4, 64
+    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
+    x, y = synth_batch(B, H, seed=98)
+    monkeypatch.setattr(engine, "BN_FOLD", False)        # fixed-order reductions: the runs must agree closely
+    plain = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+    plain.overlap_dprep = False
+    dreal = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+    dreal.overlap_dreal = True
+    default = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+    assert default.overlap_dprep and not default.overlap_dreal
+    for ts in (plain, dreal, default):
+        ts.step(x.to(DEV), y.to(DEV))
+        ts.step()
+    torch.cuda.synchronize()
+    a = plain.losses()
+    for other in (dreal, default):
+        b = other.losses()
+        for k in a:
+            assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
+        weights_agree(plain, other)
+
+
+def test_inference_with_the_fused_input_transform(monkeypatch):
+    """Forward-only plans can let the consumer of an inner BasicConv2d layer normalise that layer's raw output inside
+    its own kernel (ried_conv2d_xf; off by default: measured slower).  Same prediction and metrics as the plan that
+    writes every normalised tensor, up to bf16 rounding of tensors that are no longer stored."""
+    sd = g_state()
+    B, H = 4, 256
+    x, y = synth_batch(B, H, seed=79)
+    xd, yd = x.to(DEV), y.to(DEV)
+    a = InferenceEngine(sd, B, H, H)
+    pa, sa = a.run(xd, yd)
+    pa, ma = pa.cpu().clone(), a.measures(sa)
+    monkeypatch.setattr(engine, "XF_FUSE", True)
+    b = InferenceEngine(sd, B, H, H)
+    fused = [l for m in b.G.body.layers for l in _walk(m) if isinstance(l, engine.ConvBN) and l.core.xf_src is not None]
+    assert len(fused) >= 10, len(fused)
+    pb, sb = b.run(xd, yd)
+    pb, mb = pb.cpu(), b.measures(sb)
+    act_close(pb, pa, "fused vs separate normalisation", mx=2e-2, mean=3e-3)
+    for i in range(B):
+        for u, v in zip(mb[i][1], ma[i][1]):
+            assert abs(u - v) <= 1e-2 * abs(v) + 1e-5, (i, mb[i], ma[i])
+
+
+def _walk(layer):
+    """Every leaf layer under a Seq / Par."""
+    if isinstance(layer, engine.Seq):
+        for l in layer.layers:
+            yield from _walk(l)
+    elif isinstance(layer, engine.Par):
+        for b in layer.branches:
+            yield from _walk(b)
+    else:
+        yield layer
+
+
+def test_training_plan_with_the_pool_branch_folded(monkeypatch):
+    """RIED_POOL_FOLD_TRAIN=1: avg_pool + 1x1 of the pool branches as one 3x3 convolution also in training plans (off
+    by default: measured slower).  Same step as the default plan up to bf16 rounding (the pooled tensor is no longer
+    rounded; the weights are divided by nine before rounding)."""
+    B, H = 4, 64
+    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
+    x, y = synth_batch(B, H, seed=97)
+    base = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False)
+    monkeypatch.setenv("RIED_POOL_FOLD_TRAIN", "1")
+    fold = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False)
+    assert any(isinstance(l, engine.ConvBN) and l.core.pool_fold for m in fold.G.body.layers for l in _walk(m))
+    assert not any(isinstance(l, engine.ConvBN) and l.core.pool_fold for m in base.G.body.layers for l in _walk(m))
+    for ts in (base, fold):
+        ts.step(x.to(DEV), y.to(DEV))
+    torch.cuda.synchronize()
+    a, b = base.losses(), fold.losses()
+    for k in ("dloss1", "dloss2", "gloss", "vgg", "dssim", "gen"):
+        assert abs(a[k] - b[k]) <= 1e-2 * abs(a[k]) + 1e-4, (k, a[k], b[k])
+    act_close(fold.G.out.cpu(), base.G.out.cpu(), "prediction", mx=2e-2, mean=3e-3)
+    # the folded weights' gradients are the nine taps' sum over nine: a wrong scale shows in the norm ratio, a missing
+    # tap in the cosine (these tensors sit in front of a BatchNorm and are small, so rounding alone costs ~0.15 of it)
+    for k in ("layer_block_1.0.branch_pool.conv.weight", "layer_block_3.0.branch_pool.conv.weight"):
+        grad_close(fold.gs.g[k].cpu(), base.gs.g[k].cpu(), "G " + k, cos=0.7, ratio=0.35)
+    gf = torch.cat([fold.gs.g[k].float().flatten() for k in sorted(fold.gs.g)]).cpu()
+    gb = torch.cat([base.gs.g[k].float().flatten() for k in sorted(base.gs.g)]).cpu()
+    grad_close(gf, gb, "all generator gradients", cos=0.97, ratio=0.1)
