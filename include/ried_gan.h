@@ -205,18 +205,29 @@ int ried_bn_apply_images(const void* x, long long ldx, void* y, long long ldy, l
  * zero-initialised unsigned per layer (left at zero) - the last block of the reduction then finishes the sums.
  * folded: NULL, or ZEROED fp32 [ried_bn_backward_folded_floats(C)] owned by the layer (left non-zero): the
  * reduction's blocks add into a few rows of it with float atomics and the apply pass adds those up itself - two
- * launches instead of three, sums that depend on the order the blocks finish in; scratch and counter are unused. */
+ * launches instead of three, sums that depend on the order the blocks finish in; scratch is unused.  folded AND
+ * counter (then: a zeroed word that is LEFT NON-ZERO, e.g. a word of the same zeroed arena as folded): ONE launch -
+ * the blocks add their sums into the rows, meet at a grid barrier and apply; for layers with
+ * ried_bn_backward_fused_ok(npix, C, 1) only (a grid that is resident at once), an argument error otherwise. */
 int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
                      long long npix, int C, const float* save, const float* gamma, const float* beta, int relu,
                      float* scratch, float* dgamma, float* dbeta, int accumulate, unsigned* counter, float* folded,
                      ried_stream_t stream);
 long long ried_bn_backward_scratch_floats(int C);
 long long ried_bn_backward_folded_floats(int C);
+/* 1 when njobs layers of npix pixels and at most maxC channels each can take the one-launch form (0: too large). */
+int ried_bn_backward_fused_ok(long long npix, int maxC, int njobs);
+/* *out = blocks that gave up waiting at a grid barrier of the one-launch forms since the library was loaded: 0
+ * unless a launch could not get all its blocks resident (its results are then wrong; the wait is bounded so that
+ * the grid always drains).  Synchronises with the device.  No counterpart in the reference (a health check). */
+int ried_barrier_timeouts(unsigned* out);
 /* Job-table form: ried_bn_backward for njobs layers that share the pixel count (the sibling 1x1 layers of an
  * Inception block, src/rinet.py:99-103,225-233) in three launches in all.  jobs: device table, 16 64-bit words per
  * job: dy, lddy, x, ldx, dx, lddx, C, save, gamma, beta, act, scratch, dgamma, dbeta, accumulate, folded (meanings
  * as the arguments of ried_bn_backward; every job its own scratch or folded rows).  maxC: the largest C among the
- * jobs; all_folded: non-zero when every job carries folded rows (two launches in all). */
+ * jobs; all_folded: 1 when every job carries folded rows (two launches in all); 2 when in addition the scratch
+ * word of every job points at a zeroed barrier counter (left non-zero) and
+ * ried_bn_backward_fused_ok(npix, maxC, njobs) holds: one launch in all. */
 int ried_bn_backward_jobs(const long long* jobs, int njobs, long long npix, int maxC, int all_folded,
                           ried_stream_t stream);
 

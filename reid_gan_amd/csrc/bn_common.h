@@ -32,6 +32,34 @@ __device__ __forceinline__ bool ried_last_block(unsigned* counter, unsigned nblo
   return *lds_flag != 0;
 }
 
+// Grid-wide barrier for launches whose blocks are all resident at once (the callers bound the grid well below the
+// chip's wave slots, and kernels running beside it on other streams finish on their own, so every block does get
+// a slot).  counter: zero before the launch, left at nblocks - a word of an arena that is cleared once per pass.
+// What the blocks exchange across it must travel as agent-scope atomics on both sides (float atomic adds before,
+// ried_peek() after): no fence is issued, so plain stores are NOT ordered by it.  The wait is bounded: a block
+// that gives up counts itself in ried_barrier_timeouts and goes on, so the grid always drains.
+static __device__ unsigned ried_barrier_timeouts_dev;      // one per translation unit
+#define RIED_BARRIER_MAX_POLLS (1 << 22)
+__device__ __forceinline__ void ried_grid_barrier(unsigned* counter, unsigned nblocks) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    int polls = 0;
+    while (t < nblocks && polls < RIED_BARRIER_MAX_POLLS) {
+      __builtin_amdgcn_s_sleep(1);
+      t = __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ++polls;
+    }
+    if (t < nblocks) __hip_atomic_fetch_add(&ried_barrier_timeouts_dev, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+}
+// A value other blocks of this launch produced with agent-scope atomics before ried_grid_barrier().
+__device__ __forceinline__ float ried_peek(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 struct BnFinalize {          // train-mode BatchNorm2d statistics from [nrows][2][C] partial rows
   unsigned* counter;         // null: no fused finalize
   float* save;               // [2][C]: mean, 1/sqrt(var + eps)

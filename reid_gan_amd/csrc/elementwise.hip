@@ -674,12 +674,188 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_jobs_kernel(const lon
                       (const float*)J[7], (const float*)J[8], (const float*)J[9], (int)J[10],
                       (const float*)J[11] + (long long)BN_BWD_MAX_ROWS * 2 * C, 0, nullptr, nullptr, 0);
 }
+// ---------------------------------------------------------------------------
+// BatchNorm backward in ONE launch for layers small enough that a grid of at most BN_FUSED_MAX_BLOCKS blocks walks
+// them in a few passes: the blocks add their partial sums into the folded rows with float atomics, meet at a grid
+// barrier, add the rows up and apply.  With at most KEEP passes per thread the masked gradient and x-hat stay in
+// registers across the barrier; otherwise the second walk reads the (L2-resident) operands again.
+// ---------------------------------------------------------------------------
+#define BN_FUSED_MAX_BLOCKS 256
+#define BN_FUSED_MAX_PASSES 16
+#define BN_FUSED_KEEP 4
+template <int KEEP>
+__device__ __forceinline__ void bn_bwd_fused_body(
+    const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx,
+    bf16_t* __restrict__ dx, long long lddx, long long npix, int C, const float* __restrict__ save,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, float* __restrict__ folded,
+    unsigned* counter, float* dgamma, float* dbeta, int accumulate) {
+  __shared__ float red[EW_THREADS][17];
+  ChanWalk w(C);
+  const int c = w.c;
+  float s1[8], s2[8], a[8], b[8], mean[8], istd[8];
+  float kg[KEEP ? KEEP : 1][8], kx[KEEP ? KEEP : 1][8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  if (w.active) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mean[q] = save[c + q]; istd[q] = save[C + c + q];
+      a[q] = gamma[c + q] * istd[q]; b[q] = beta[c + q];
+    }
+    if (KEEP) {
+      u32x4 vg[KEEP ? KEEP : 1], vx[KEEP ? KEEP : 1];
+#pragma unroll
+      for (int k = 0; k < KEEP; ++k) {
+        const long long p = w.p + k * w.step;
+        if (p < npix) { vg[k] = ld8(dy + p * lddy + c); vx[k] = ld8(x + p * ldx + c); }
+      }
+#pragma unroll
+      for (int k = 0; k < KEEP; ++k) {
+        const long long p = w.p + k * w.step;
+        float g[8], xv[8];
+        if (p < npix) { unpack8(vg[k], g); unpack8(vx[k], xv); }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float d = p < npix ? xv[q] - mean[q] : 0.f;
+          float gg = p < npix ? bn_act_grad(d * a[q] + b[q], g[q], relu) : 0.f;
+          kg[k][q] = gg; kx[k][q] = d * istd[q];
+          s1[q] += gg; s2[q] += gg * kx[k][q];
+        }
+      }
+    } else {
+#pragma unroll 2
+      for (long long p = w.p; p < npix; p += w.step) {
+        float g[8], xv[8];
+        unpack8(ld8(dy + p * lddy + c), g);
+        unpack8(ld8(x + p * ldx + c), xv);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float d = xv[q] - mean[q];
+          float gg = bn_act_grad(d * a[q] + b[q], g[q], relu);
+          s1[q] += gg; s2[q] += gg * (d * istd[q]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { red[threadIdx.x][q] = s1[q]; red[threadIdx.x][8 + q] = s2[q]; }
+  __syncthreads();
+  const int CC = C >> 3, PPB = EW_THREADS / CC;
+  float* row = folded + (long long)(blockIdx.x % BN_BWD_FOLD_ROWS) * 2 * C;
+  for (int j = threadIdx.x; j < 2 * C; j += EW_THREADS) {
+    int k = j >= C, ch = j - k * C;
+    int t0 = ch >> 3, q = (ch & 7) + 8 * k;
+    float acc = 0.f;
+    for (int pl = 0; pl < PPB; ++pl) acc += red[pl * CC + t0][q];
+    __hip_atomic_fetch_add(&row[j], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  ried_grid_barrier(counter, gridDim.x);
+  // every block adds the rows up for all channels (through LDS: [2][C] floats fit the reduction's array)
+  float* tot = &red[0][0];
+  for (int j = threadIdx.x; j < 2 * C; j += EW_THREADS) {
+    float t = 0.f;
+#pragma unroll
+    for (int r = 0; r < BN_BWD_FOLD_ROWS; ++r) t += ried_peek(folded + (long long)r * 2 * C + j);
+    tot[j] = t;
+    if (blockIdx.x == 0 && dgamma) {
+      float* dst = j >= C ? dgamma + (j - C) : dbeta + j;
+      *dst = accumulate ? *dst + t : t;
+    }
+  }
+  __syncthreads();
+  if (!w.active) return;
+  const float invn = 1.f / (float)npix;
+  float m1[8], m2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { m1[q] = tot[c + q] * invn; m2[q] = tot[C + c + q] * invn; }
+  if (KEEP) {
+#pragma unroll
+    for (int k = 0; k < KEEP; ++k) {
+      const long long p = w.p + k * w.step;
+      float o[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) o[q] = a[q] * (kg[k][q] - m1[q] - kx[k][q] * m2[q]);
+      if (p < npix) st8(dx + p * lddx + c, pack8(o));
+    }
+  } else {
+#pragma unroll 2
+    for (long long p = w.p; p < npix; p += w.step) {
+      float g[8], xv[8];
+      unpack8(ld8(dy + p * lddy + c), g);
+      unpack8(ld8(x + p * ldx + c), xv);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float d = xv[q] - mean[q];
+        float gg = bn_act_grad(d * a[q] + b[q], g[q], relu);
+        g[q] = a[q] * (gg - m1[q] - d * istd[q] * m2[q]);
+      }
+      st8(dx + p * lddx + c, pack8(g));
+    }
+  }
+}
+template <int KEEP>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_fused_kernel(
+    const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx,
+    bf16_t* __restrict__ dx, long long lddx, long long npix, int C, const float* __restrict__ save,
+    const float* __restrict__ gamma, const float* __restrict__ beta, int relu, float* __restrict__ folded,
+    unsigned* counter, float* dgamma, float* dbeta, int accumulate) {
+  bn_bwd_fused_body<KEEP>(dy, lddy, x, ldx, dx, lddx, npix, C, save, gamma, beta, relu, folded, counter, dgamma, dbeta,
+                          accumulate);
+}
+// jobs as ried_bn_backward_jobs; word 11 is the job's barrier counter, word 15 its folded rows
+template <int KEEP>
+__global__ __launch_bounds__(EW_THREADS) void bn_bwd_fused_jobs_kernel(const long long* __restrict__ jobs,
+                                                                       long long npix) {
+  const long long* J = jobs + (long long)blockIdx.y * BN_JOB_WORDS;
+  float* dg = (J[12] && J[13]) ? (float*)J[12] : nullptr;
+  bn_bwd_fused_body<KEEP>((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], (bf16_t*)J[4], J[5], npix, (int)J[6],
+                          (const float*)J[7], (const float*)J[8], (const float*)J[9], (int)J[10], (float*)J[15],
+                          (unsigned*)J[11], dg, (float*)J[13], (int)J[14]);
+}
+// blocks per job of the one-launch form, 0 when the layers are too large for it
+static inline int bn_fused_grid(long long npix, int maxC, int njobs, int* passes) {
+  if (njobs <= 0 || njobs > BN_FUSED_MAX_BLOCKS || maxC < 8 || maxC > 8 * EW_THREADS || npix <= 0) return 0;
+  const int ppb = EW_THREADS / (maxC >> 3);               // pixels per block pass of the widest layer
+  const int grid = ew_grid(npix, ppb, BN_FUSED_MAX_BLOCKS / njobs);
+  const long long per_pass = (long long)grid * ppb;       // (narrower layers cover more pixels per pass)
+  const long long np = (npix + per_pass - 1) / per_pass;
+  if (np > BN_FUSED_MAX_PASSES) return 0;
+  *passes = (int)np;
+  return grid;
+}
+extern "C" int ried_bn_backward_fused_ok(long long npix, int maxC, int njobs) {
+  int passes = 0;
+  return bn_fused_grid(npix, maxC, njobs, &passes) > 0;
+}
+// Blocks that gave up waiting at a grid barrier since the library was loaded (0 unless a launch could not get all
+// its blocks resident: its results are then wrong).  Synchronises with the device.
+extern "C" int ried_barrier_timeouts(unsigned* out) {
+  RIED_CHECK_ARG(out, "ried_barrier_timeouts: null argument");
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ried_barrier_timeouts_dev), sizeof(unsigned)) != hipSuccess) {
+    ried_set_error("ried_barrier_timeouts: copy failed");
+    return RIED_ERR_HIP;
+  }
+  return RIED_OK;
+}
+
 // jobs: device table of njobs records; maxC: the largest channel count among them (sizes the grids);
 // all_folded: every job carries folded rows, so the launch that finishes the per-block rows is left out
 extern "C" int ried_bn_backward_jobs(const long long* jobs, int njobs, long long npix, int maxC, int all_folded,
                                      hipStream_t stream) {
   RIED_CHECK_ARG(jobs && njobs > 0 && njobs <= 65535 && npix > 0 && maxC >= 8 && maxC % 8 == 0 && maxC <= 8 * EW_THREADS,
                  "ried_bn_backward_jobs: bad arguments");
+  if (all_folded == 2) {        // one launch: word 11 of every job is its zeroed barrier counter
+    int passes = 0;
+    const int fg = bn_fused_grid(npix, maxC, njobs, &passes);
+    RIED_CHECK_ARG(fg > 0, "ried_bn_backward_jobs: layers too large for the one-launch form");
+    if (passes <= BN_FUSED_KEEP)
+      hipLaunchKernelGGL(bn_bwd_fused_jobs_kernel<BN_FUSED_KEEP>, dim3(fg, njobs), dim3(EW_THREADS), 0, stream, jobs,
+                         npix);
+    else
+      hipLaunchKernelGGL(bn_bwd_fused_jobs_kernel<0>, dim3(fg, njobs), dim3(EW_THREADS), 0, stream, jobs, npix);
+    RIED_CHECK_LAUNCH("ried_bn_backward_jobs");
+    return RIED_OK;
+  }
   const int grid = chan_grid(npix, maxC, 4, BN_BWD_MAX_ROWS);
   hipLaunchKernelGGL(bn_bwd_reduce_jobs_kernel, dim3(grid, njobs), dim3(EW_THREADS), 0, stream, jobs, npix);
   if (!all_folded)
@@ -707,6 +883,21 @@ extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, l
   RIED_CHECK_ARG(C <= 8 * EW_THREADS, "ried_bn_backward: C too large");
   int grid = chan_grid(npix, C, 4, BN_BWD_MAX_ROWS);
   float* dg = (dgamma && dbeta) ? dgamma : nullptr;
+  if (folded && counter) {
+    int passes = 0;
+    const int fg = bn_fused_grid(npix, C, 1, &passes);
+    RIED_CHECK_ARG(fg > 0, "ried_bn_backward: layer too large for the one-launch form (ried_bn_backward_fused_ok)");
+    if (passes <= BN_FUSED_KEEP)
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<BN_FUSED_KEEP>, dim3(fg), dim3(EW_THREADS), 0, stream, (const bf16_t*)dy,
+                         lddy, (const bf16_t*)x, ldx, (bf16_t*)dx, lddx, npix, C, save, gamma, beta, relu, folded,
+                         counter, dg, dbeta, accumulate);
+    else
+      hipLaunchKernelGGL(bn_bwd_fused_kernel<0>, dim3(fg), dim3(EW_THREADS), 0, stream, (const bf16_t*)dy, lddy,
+                         (const bf16_t*)x, ldx, (bf16_t*)dx, lddx, npix, C, save, gamma, beta, relu, folded, counter,
+                         dg, dbeta, accumulate);
+    RIED_CHECK_LAUNCH("ried_bn_backward");
+    return RIED_OK;
+  }
   if (folded) {
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, (const bf16_t*)dy, lddy,
                        (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, (float*)nullptr, (unsigned*)nullptr,

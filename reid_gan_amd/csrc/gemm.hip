@@ -1065,9 +1065,12 @@ __global__ __launch_bounds__(512, NBB == 1 ? 4 : 2) void conv_halo_kernel(const 
   }
 #pragma unroll
   for (int i = 0; i < NLB; ++i) {
-    const int ci = i * 512 + tid, hr = ci >> 3, q = (ci & 7) ^ (hr & 7);
+    const int ci = i * 512 + tid, hr = ci >> 3;
     const int il = hr / HRI, hp = hr - il * HRI;
     const int hy = hp / TWP, hx = hp - hy * TWP;
+    // chunk swizzle by the row number for 18-pixel tile rows, by the column for 10-pixel ones (a fragment read
+    // takes 8 + 8 pixels of two tile rows there: rows 10 apart have the same parity and collide two-way)
+    const int q = (ci & 7) ^ ((TS == 8 ? hx : hr) & 7);
     const int iy = ty0 + hy - 1, ix = tx0 + hx - 1;
     const bool ok = hr < HR && img0 + il < X.nimg && (unsigned)iy < (unsigned)X.H && (unsigned)ix < (unsigned)X.W;
     boff[i] = ok ? (unsigned)(((img0 + il) * X.H + iy) * X.W + ix) * (unsigned)X.ld * 2u + (unsigned)q * 16u : B_OOB;
@@ -1098,6 +1101,7 @@ __global__ __launch_bounds__(512, NBB == 1 ? 4 : 2) void conv_halo_kernel(const 
   const int kq0 = lane >> 4, kq1 = 4 + (lane >> 4);
   const int sw0 = (kq0 ^ (lane & 7)) << 4, sw1 = (kq1 ^ (lane & 7)) << 4;
   int hr0[TN];                       // LDS row of this lane's pixel (n = wn*64 + j*16 + lane%16) before the tap shift
+  const int hx0 = lane & 7;          // TS == 8: its column in the tile (16 consecutive pixels = two tile rows)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nl = wn * 64 + j * 16 + (lane & 15);
@@ -1105,7 +1109,7 @@ __global__ __launch_bounds__(512, NBB == 1 ? 4 : 2) void conv_halo_kernel(const 
     hr0[j] = il * HRI + (p / TS) * TWP + (p % TS);
   }
   bf16x8_t fa[2][TM], fb[2][TN];
-  auto load_frags = [&](int stage, int bbuf, int toff, int ks) {
+  auto load_frags = [&](int stage, int bbuf, int toff, int tcol, int ks) {
     const char* sa = sA + stage * ABUF + wm * (BM / 2) * 128 + frow;
     const char* sb = sB + bbuf * BBUF;
 #pragma unroll
@@ -1113,7 +1117,8 @@ __global__ __launch_bounds__(512, NBB == 1 ? 4 : 2) void conv_halo_kernel(const 
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int hr = hr0[j] + toff;
-      fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + hr * 128 + (((ks ? kq1 : kq0) ^ (hr & 7)) << 4));
+      const int swz = (TS == 8 ? hx0 + tcol : hr) & 7;
+      fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + hr * 128 + (((ks ? kq1 : kq0) ^ swz) << 4));
     }
   };
   auto mfmas = [&](int ks) {
@@ -1140,11 +1145,12 @@ __global__ __launch_bounds__(512, NBB == 1 ? 4 : 2) void conv_halo_kernel(const 
       __builtin_amdgcn_s_barrier();
       const int r = tap / 3, c = tap - r * 3;
       const int toff = flip ? (2 - r) * TWP + (2 - c) : r * TWP + c;
-      load_frags(tap % 3, slab & (NBB - 1), toff, 0);
+      const int tcol = flip ? 2 - c : c;
+      load_frags(tap % 3, slab & (NBB - 1), toff, tcol, 0);
       if (tap < 7) issueA(slab, tap + 2, (tap + 2) % 3);
       else issueA(slab + 1, tap - 7, (tap + 2) % 3);
       if (tap < PARTS) issueB(slab + 1, tap);
-      load_frags(tap % 3, slab & (NBB - 1), toff, 1);
+      load_frags(tap % 3, slab & (NBB - 1), toff, tcol, 1);
       mfmas(0);
       mfmas(1);
     }

@@ -542,15 +542,17 @@ class ConvBN:
         self.draw: Optional[View] = None
         if fwd_member:
             grp.join(self)
-        self.bwd_fold = False
+        self.bwd_fold = self.bwd_one = False
         if ctx.grads:
             ctx.need_f32(ops.bn_backward_scratch_floats(cout))
             if bias:
                 ctx.need_f32(ops.colsum_scratch_floats(cout))
             # small layers: the backward sums are folded with float atomics too (one dependent launch fewer)
             self.bwd_fold = BN_FOLD and BN_BWD_FOLD and self.raw.npix * cout <= BN_FOLD_MAX_ELEMS
-            if self.bwd_fold:
-                ctx.stats(self, "bfold", ops.bn_backward_folded_floats(cout), zeroed="backward")
+            if self.bwd_fold:     # (+ 8 words: the grid barrier's counter of the one-launch form sits behind the rows)
+                self.bfold_rows = ops.bn_backward_folded_floats(cout)     # (ctx.stats sets bfold_n = the whole request)
+                ctx.stats(self, "bfold", self.bfold_rows + 8, zeroed="backward")
+            self.bwd_one = self.bwd_fold and BN_BWD_ONE and ops.bn_backward_fused_ok(self.raw.npix, cout, 1)
             # the gradient w.r.t. the conv output keeps its own buffer, so that the weight gradient can wait for
             # the grouped launch at the end of the backward pass
             if grouped:
@@ -625,7 +627,8 @@ class ConvBN:
         ctx, st = self.ctx, self.ctx.st
         ops.bn_backward(self.out.g, self.raw, self.draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
                         ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=self.act,
-                        accumulate=self.shared, folded=self.bfold if self.bwd_fold else None)
+                        accumulate=self.shared, folded=self.bfold if self.bwd_fold else None,
+                        counter=self.bfold[self.bfold_rows:] if self.bwd_one else None)
 
     # ---- pieces for Par's level-wise job tables (small train-mode layers only) ----
     def level_ok(self) -> bool:
@@ -663,8 +666,9 @@ class ConvBN:
         if not self.bwd_fold and getattr(self, "_bn_scratch", None) is None:
             self._bn_scratch = torch.empty(ops.bn_backward_scratch_floats(self.core.cout), dtype=F32,
                                            device=self.ctx.device)
+        # (the scratch word of a folded job carries its barrier counter: read by the one-launch form only)
         return ops.bn_backward_job(self.out.g, self.raw, self.draw, self.save, st.p[bn + ".weight"],
-                                   st.p[bn + ".bias"], None if self.bwd_fold else self._bn_scratch,
+                                   st.p[bn + ".bias"], self.bfold[self.bfold_rows:] if self.bwd_fold else self._bn_scratch,
                                    st.g[bn + ".weight"], st.g[bn + ".bias"], act=self.act, accumulate=self.shared,
                                    folded=self.bfold if self.bwd_fold else None)
 
@@ -788,13 +792,14 @@ class InputGradGroup:
     def _make_bn_jobs(self):
         st = self.ctx.st
         rows = [ops.bn_backward_job(m.out.g, m.raw, m.draw, m.save, st.p[m.bn + ".weight"], st.p[m.bn + ".bias"],
-                                    m._bn_scratch, st.g[m.bn + ".weight"], st.g[m.bn + ".bias"], act=m.act,
-                                    accumulate=m.shared, folded=m.bfold if m.bwd_fold else None)
+                                    m.bfold[m.bfold_rows:] if m.bwd_fold else m._bn_scratch, st.g[m.bn + ".weight"],
+                                    st.g[m.bn + ".bias"], act=m.act, accumulate=m.shared,
+                                    folded=m.bfold if m.bwd_fold else None)
                 for m in self.members]
-        self.bn_all_folded = all(m.bwd_fold for m in self.members)
         self.bn_jobs = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
         self.bn_maxc = max(m.core.cout for m in self.members)
         self.npix = self.drawcat.npix
+        self.bn_all_folded = bn_jobs_mode(self.members, self.npix, self.bn_maxc)
 
     def _make_fwd_jobs(self):
         st, rows, c0, cs = self.ctx.st, [], 0, []
@@ -824,6 +829,14 @@ class InputGradGroup:
         ops.conv2d(self.drawcat, self.wcat, self.xin.g, 1, 1, 1, 1, 0, 0, transposed=True, accumulate=True)
 
 
+def bn_jobs_mode(layers, npix: int, maxc: int) -> int:
+    """The all_folded argument of ops.bn_backward_jobs for these layers: 0 per-block rows, 1 folded rows (two
+    launches), 2 folded rows and one launch with a grid barrier (layers small enough for it)."""
+    if not all(l.bwd_fold for l in layers):
+        return 0
+    return 2 if BN_BWD_ONE and ops.bn_backward_fused_ok(npix, maxc, len(layers)) else 1
+
+
 SIBLING_GROUPS = not os.environ.get("RIED_NO_SIBLING_GROUPS")      # switch for A/B runs and tests
 FUSED_ATTN = not os.environ.get("RIED_NO_FUSED_ATTN")
 PACK_TILES = not os.environ.get("RIED_NO_PACK_TILES")
@@ -831,6 +844,10 @@ FWD_BN_JOBS = not os.environ.get("RIED_NO_FWD_BN_JOBS")
 BN_BWD_FOLD = not os.environ.get("RIED_NO_BN_BWD_FOLD")
 LEVEL_JOBS = not os.environ.get("RIED_NO_LEVEL_JOBS")
 POOL_FOLD = not os.environ.get("RIED_NO_POOL_FOLD")
+# BatchNorm backward of small layers as one launch (partial sums, grid barrier, apply) instead of two.  Off: measured
+# 7.81 against 7.79 ms per step - the barrier's atomic round trips cost what the launch boundary they replace costs
+# (43 launches fewer per step; RIED_BN_BWD_ONE=1 turns it on).
+BN_BWD_ONE = bool(os.environ.get("RIED_BN_BWD_ONE"))
 
 
 def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
@@ -1025,8 +1042,8 @@ class Par:
             # backward: BatchNorms, then data gradients (level 0: the branches' inputs are one tensor - one by one)
             lv["bwd_bn"], lv["bwd_bn_single"] = self._bn_tables(
                 [(l, l.bwd_bn_job()) for l in ok if not l.bn_bwd_grouped], dev)
-            lv["bwd_all_folded"] = {n: all(l.bwd_fold for l in ok if not l.bn_bwd_grouped and l.raw.npix == n)
-                                    for n in lv["bwd_bn"]}
+            lv["bwd_all_folded"] = {n: bn_jobs_mode([l for l in ok if not l.bn_bwd_grouped and l.raw.npix == n], n, t[2])
+                                    for n, t in lv["bwd_bn"].items()}
             bc = ops.ConvJobs()
             dgs = [l for l in ok if l.core.need_dx] if k > 0 else []
             if len(dgs) >= 2:

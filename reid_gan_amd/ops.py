@@ -382,7 +382,8 @@ def bn_backward(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma=
                 accumulate=False, counter: Optional[torch.Tensor] = None, folded: Optional[torch.Tensor] = None):
     """scratch: fp32, at least bn_backward_scratch_floats(C) elements.  counter: a zeroed int32 element owned by
     the layer; with it the reduction's last block finishes the sums (one launch fewer).  folded: zeroed fp32
-    [bn_backward_folded_floats(C)] owned by the layer (left non-zero): two launches, atomically folded sums."""
+    [bn_backward_folded_floats(C)] owned by the layer (left non-zero): two launches, atomically folded sums.
+    folded and counter (a zeroed word, left non-zero): one launch with a grid barrier, bn_backward_fused_ok() layers."""
     lib.ried_bn_backward(dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta),
                          int(relu), _p(scratch), _p(dgamma), _p(dbeta), int(accumulate), _p(counter), _p(folded),
                          _stream())
@@ -392,6 +393,19 @@ def bn_backward_folded_floats(C: int) -> int:
     return lib.ried_bn_backward_folded_floats(C)
 
 
+def bn_backward_fused_ok(npix: int, maxC: int, njobs: int = 1) -> bool:
+    """Whether njobs layers of npix pixels and at most maxC channels are small enough for the one-launch backward."""
+    return bool(lib.ried_bn_backward_fused_ok(npix, maxC, njobs))
+
+
+def barrier_timeouts() -> int:
+    """Blocks that gave up waiting at a grid barrier since the library was loaded (0 in a healthy process)."""
+    import ctypes
+    n = ctypes.c_uint(0)
+    lib.ried_barrier_timeouts(ctypes.addressof(n))
+    return n.value
+
+
 def bn_backward_job(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma, dbeta, act=1, accumulate=False,
                     folded: Optional[torch.Tensor] = None):
     """One 16-word record of the table bn_backward_jobs takes."""
@@ -399,8 +413,10 @@ def bn_backward_job(dy: View, x: View, dx: View, save, gamma, beta, scratch, dga
             _p(scratch) or 0, _p(dgamma) or 0, _p(dbeta) or 0, int(accumulate), _p(folded) or 0]
 
 
-def bn_backward_jobs(table: torch.Tensor, njobs: int, npix: int, maxC: int, all_folded: bool = False):
-    """table: int64 device tensor [njobs][16] of bn_backward_job records (layers sharing the pixel count)."""
+def bn_backward_jobs(table: torch.Tensor, njobs: int, npix: int, maxC: int, all_folded: int = 0):
+    """table: int64 device tensor [njobs][16] of bn_backward_job records (layers sharing the pixel count).
+    all_folded: 1 every job has folded rows (two launches); 2 also a zeroed barrier counter in its scratch word and
+    bn_backward_fused_ok(npix, maxC, njobs) holds (one launch)."""
     lib.ried_bn_backward_jobs(_p(table), njobs, npix, maxC, int(all_folded), _stream())
 
 

@@ -623,6 +623,31 @@ def test_optional_step_overlaps_give_the_same_step(monkeypatch):
         weights_agree(plain, other)
 
 
+def test_training_plan_with_the_one_launch_batchnorm_backward(monkeypatch):
+    """RIED_BN_BWD_ONE=1: the BatchNorm backward of small layers as one launch with a grid barrier (off by default:
+    measured equal).  The same folded sums in another order: the step agrees with the default plan up to the rounding
+    of those sums, the launch count drops, and no block ever gave up at a barrier."""
+    B, H = 4, 64
+    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
+    x, y = synth_batch(B, H, seed=96)
+    base = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+    monkeypatch.setattr(engine, "BN_BWD_ONE", True)
+    one = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+    n_one = sum(1 for m in one.G.body.layers for l in _walk(m) if isinstance(l, engine.ConvBN) and l.bwd_one)
+    assert n_one >= 40, n_one
+    assert not any(isinstance(l, engine.ConvBN) and l.bwd_one for m in base.G.body.layers for l in _walk(m))
+    for ts in (base, one):
+        ts.step(x.to(DEV), y.to(DEV))
+    torch.cuda.synchronize()
+    a, b = base.losses(), one.losses()
+    for k in ("dloss1", "dloss2", "gloss", "vgg", "dssim", "gen"):
+        assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-5, (k, a[k], b[k])
+    gf = torch.cat([one.gs.g[k].float().flatten() for k in sorted(one.gs.g)]).cpu()
+    gb = torch.cat([base.gs.g[k].float().flatten() for k in sorted(base.gs.g)]).cpu()
+    grad_close(gf, gb, "all generator gradients", cos=0.98, ratio=0.05)
+    assert ops.barrier_timeouts() == 0
+
+
 def test_inference_with_the_fused_input_transform(monkeypatch):
     """Forward-only plans can let the consumer of an inner BasicConv2d layer normalise that layer's raw output inside
     its own kernel (ried_conv2d_xf; off by default: measured slower).  Same prediction and metrics as the plan that

@@ -558,6 +558,77 @@ def test_bn_forward_backward():
     assert (dx3.torch().float() - dxv.torch().float()).abs().max() <= 2e-2 * dxv.torch().float().abs().max()
 
 
+def _bn_case(N, C, H, seed):
+    x = (r(N, C, H, H, seed=seed) * 2 + 0.5).to(torch.bfloat16).float()
+    gamma, beta = r(C, seed=seed + 1) + 1.0, r(C, seed=seed + 2) * 0.3
+    dy = r(N, C, H, H, seed=seed + 3).to(torch.bfloat16).float()
+    mean, var = x.mean((0, 2, 3)), x.var((0, 2, 3), unbiased=False)
+    save = torch.stack([mean, (var + 1e-5).rsqrt()]).to(DEV).contiguous()
+    return x, dy, gamma.to(DEV), beta.to(DEV), save
+
+
+@pytest.mark.parametrize("N,C,H", [(4, 48, 8), (2, 8, 4), (32, 64, 16), (128, 64, 32), (16, 1024, 4)])
+def test_bn_backward_in_one_launch(N, C, H):
+    """folded + counter: partial sums, grid barrier and apply in one launch (the register-resident variant for at
+    most four passes per thread, the re-reading one above), against the two-launch folded form; repeated with the
+    same (re-zeroed) rows, and refused for a layer that is too large."""
+    assert ops.bn_backward_fused_ok(N * H * H, C)
+    x, dy, gamma, beta, save = _bn_case(N, C, H, 400 + C)
+    xv, dyv = to_view(x), to_view(dy)
+    nf = ops.bn_backward_folded_floats(C)
+    ref_dx = ops.new_view(N, H, H, C)
+    rg, rb = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    ops.bn_backward(dyv, xv, ref_dx, save, gamma, beta, None, rg, rb, folded=torch.zeros(nf, device=DEV))
+    buf = torch.zeros(nf + 8, device=DEV)
+    for rep in range(2):
+        buf.zero_()
+        dx = ops.new_view(N, H, H, C)
+        dx.torch().fill_(float("nan"))
+        dg, db = torch.ones(C, device=DEV), torch.ones(C, device=DEV)
+        ops.bn_backward(dyv, xv, dx, save, gamma, beta, None, dg, db, accumulate=True, folded=buf, counter=buf[nf:])
+        torch.cuda.synchronize()
+        a, b = dx.torch().float(), ref_dx.torch().float()
+        assert torch.isfinite(a).all()
+        assert (a - b).abs().max() <= 2e-2 * b.abs().max() + 1e-6, (rep, (a - b).abs().max().item())
+        close(dg.cpu() - 1, rg.cpu(), 5e-3, "dgamma")
+        close(db.cpu() - 1, rb.cpu(), 5e-3, "dbeta")
+    assert ops.barrier_timeouts() == 0
+    assert not ops.bn_backward_fused_ok(128 * 64 * 64, 64)
+    with pytest.raises(RuntimeError, match="too large"):
+        big = ops.new_view(128, 64, 64, 64)
+        ops.bn_backward(big, big, big, save, gamma, beta, None, folded=buf, counter=buf[nf:])
+
+
+def test_bn_backward_jobs_in_one_launch():
+    """Job table with all_folded = 2: layers of different widths sharing the pixel count, one launch."""
+    N, H = 8, 8
+    Cs = [64, 96, 16, 384]
+    assert ops.bn_backward_fused_ok(N * H * H, max(Cs), len(Cs))
+    rows, keep, want = [], [], []
+    for i, C in enumerate(Cs):
+        x, dy, gamma, beta, save = _bn_case(N, C, H, 500 + 10 * i)
+        xv, dyv = to_view(x), to_view(dy)
+        nf = ops.bn_backward_folded_floats(C)
+        ref_dx = ops.new_view(N, H, H, C)
+        rg, rb = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        ops.bn_backward(dyv, xv, ref_dx, save, gamma, beta, None, rg, rb, folded=torch.zeros(nf, device=DEV))
+        buf = torch.zeros(nf + 8, device=DEV)
+        dx = ops.new_view(N, H, H, C)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        rows.append(ops.bn_backward_job(dyv, xv, dx, save, gamma, beta, buf[nf:], dg, db, act=1, folded=buf))
+        keep.append((xv, dyv, gamma, beta, save, buf))
+        want.append((dx, ref_dx, dg, rg, db, rb))
+    table = torch.tensor(rows, dtype=torch.int64).to(DEV)
+    ops.bn_backward_jobs(table, len(Cs), N * H * H, max(Cs), 2)
+    torch.cuda.synchronize()
+    for dx, ref_dx, dg, rg, db, rb in want:
+        a, b = dx.torch().float(), ref_dx.torch().float()
+        assert (a - b).abs().max() <= 2e-2 * b.abs().max() + 1e-6
+        close(dg.cpu(), rg.cpu(), 5e-3, "dgamma")
+        close(db.cpu(), rb.cpu(), 5e-3, "dbeta")
+    assert ops.barrier_timeouts() == 0
+
+
 @pytest.mark.parametrize("C,cin,H", [(48, 32, 8), (160, 64, 8), (16, 64, 16), (1024, 64, 4)])
 def test_bn_small_layer_kernels(C, cin, H):
     """conv with folded (atomic) statistics -> bn_apply_train, against torch and the finalize + apply pair."""
