@@ -416,6 +416,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="patches per GPU")
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="prepare every step's targets inside that step (default on one GPU: at the end of the step before)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
@@ -447,7 +449,7 @@ def main():
 
     g, d, vgg = synth_states()
     ts = TrainStep(g, d, vgg, args.batch, args.size, args.size, lr=1e-4, use_graph=not args.no_graph,
-                   process_group=pg)
+                   process_group=pg, lookahead=not args.no_lookahead)
     if os.environ.get("RIED_HANG_DUMP"):
         import threading
 
@@ -490,7 +492,11 @@ def main():
         "config": {"workload": f"BASELINE configs[1]: full RIED-GAN training step, batch {args.batch} of "
                                f"1x{args.size}x{args.size} patches per GPU, bf16 storage / fp32 accumulate",
                    "global_batch": world * args.batch, "patch": args.size, "parallelism": f"dp{world}",
-                   "hip_graph": not args.no_graph, "losses": losses, "losses_first_step": first},
+                   "hip_graph": not args.no_graph,
+                   # every timed step does the whole step's work; with look-ahead the part that needs only the target
+                   # batch (VGG target features, D's weight preparation and target-half pass) is the NEXT step's,
+                   # run at the end of this one beside the generator backward
+                   "lookahead": ts.lookahead, "losses": losses, "losses_first_step": first},
     }
     if args.size == 64:
         out["step_mfma_frac"] = value / world * FLOP_PER_PATCH_64 / PEAK_MFMA_BF16

@@ -128,4 +128,6 @@ def restore(ts, ck: dict, optimizers: bool = True) -> dict:
         groups = ck["optG_state_dict"].get("param_groups") or []
         if groups and "lr" in groups[0]:
             ts.lr = float(groups[0]["lr"])
+    if hasattr(ts, "weights_changed"):
+        ts.weights_changed()          # a look-ahead plan has prepared its next step with the old weights
     return {k: ck.get(k) for k in ("epoch", "total_iters", "lr")}

@@ -20,6 +20,14 @@ backward pass completes them (bottleneck + decoder: 81 % of the parameters; then
 discriminator gradient and the generator's first bucket are exchanged WHILE the second half of the generator
 backward runs: each all-reduce is started the moment its gradients are complete and only waited for in front of the
 Adam steps.  BatchNorm statistics stay per replica.
+
+Look-ahead (lookahead=True, one rank): everything a step does that needs only the TARGET batch and weights that are
+final before the step starts - the VGG features of the targets, the first discriminator iteration's spectral norms
+and weight repacks, its pass over the target half of cat([y, pred]) - is done for the NEXT batch at the end of the
+current step, on the stream of the last discriminator backward, beside the generator backward (some 270 small
+dependent kernels that leave most of the chip idle).  step(x, y, y_next) takes the next batch's targets the way a
+prefetching loader has them; a step whose y is not the y_next announced before (or the first one) prepares its own
+targets first, so the results never depend on the announcement - only the speed does.
 """
 from __future__ import annotations
 
@@ -56,7 +64,7 @@ def _retain(graph):
 class TrainStep:
     def __init__(self, g_sd: Dict[str, torch.Tensor], d_sd: Dict[str, torch.Tensor], vgg: Dict[str, torch.Tensor],
                  batch: int, H: int, W: int, lr: float = 1e-4, weights=(0.3, 0.5, 0.2), device="cuda",
-                 use_graph: bool = True, process_group=None):
+                 use_graph: bool = True, process_group=None, lookahead: bool = False):
         ops.require_gpu()
         self.B, self.H, self.W, self._lr = batch, H, W, float(lr)
         self.wv, self.ws, self.wg = weights
@@ -98,6 +106,19 @@ class TrainStep:
         self._d_side = None
         self.overlap_dprep = not os.environ.get("RIED_NO_OVERLAP_DPREP")
         self._d_prepared = False
+        # look-ahead: see the module docstring.  With a process group the discriminator's Adam step waits for an
+        # all-reduce that is only awaited after the generator backward, so there is nothing to run the work beside.
+        self.lookahead = bool(lookahead) and process_group is None and not os.environ.get("RIED_NO_LOOKAHEAD")
+        self.pre_dreal = self.lookahead and self.D.splittable and not os.environ.get("RIED_NO_PRE_DREAL")
+        # which of the target-only pieces run at the end of the previous step (the others: beside the generator forward)
+        self.la_vgg = self.lookahead and not os.environ.get("RIED_LA_VGG_FRONT")
+        self.la_dreal = self.pre_dreal and not os.environ.get("RIED_LA_DREAL_FRONT")
+        self.y_next = torch.zeros(B, 1, H, W, dtype=F32, device=device) if self.lookahead else None
+        self._primed = False        # the targets in self.y have been prepared (by the previous step, or by _prime())
+        self._d_ready = False       # the discriminator's weights are prepared for the next step's first iteration
+        self._next_key = None       # identifies the tensor announced as y_next
+        self._ynext_is_y = False    # the y_next buffer holds a copy of self.y (nothing was announced)
+        self._warmed = False        # every kernel of the step has been loaded (an eager step has run)
         self.graphs = None          # [(graph, tensor to all-reduce after it or None)]
         self.steps_done = 0
         self.segment = -1
@@ -163,7 +184,9 @@ class TrainStep:
 
     def _d_iteration(self, last: bool):
         B, sc, D = self.B, self.sc, self.D
-        if not last and self._d_side is None and self._d_prepared:
+        if not last and self.pre_dreal:
+            out = D.forward_images(self.d_in, B, 2 * B)      # the target half ran at the end of the previous step
+        elif not last and self._d_side is None and self._d_prepared:
             out = D.forward_images(self.d_in, 0, 2 * B)      # spectral norms and repacks ran beside the generator forward
         elif last or self._d_side is None:
             out = D.forward(self.d_in)
@@ -190,6 +213,10 @@ class TrainStep:
             ops.fill(out.g.images(0, B), 1.0, s=sc[SC_CPOS:])
             ops.fill(out.g.images(B, 2 * B), 1.0, s=sc[SC_CNEG:])
             D.backward(0, 2 * B, wgrad=True)
+            if last and self.lookahead:      # D is final for this step: the next batch's targets, beside the G backward
+                self.ds.adam(4.0 * self.lr)
+                self.y.copy_(self.y_next)
+                self._prep_targets()
         if not last:
             yield [("sync", self.ds.flat_grad)]
             self.ds.adam(4.0 * self.lr)
@@ -205,7 +232,22 @@ class TrainStep:
             if b == 0:      # the last bucket: everything is needed next
                 ev += [("wait", "d")] + [("wait", ("g", k)) for k in reversed(range(len(gr)))]
             yield ev
-        self.ds.adam(4.0 * self.lr)
+        if self.lookahead:
+            self._join(side)
+        else:
+            self.ds.adam(4.0 * self.lr)
+
+    def _prep_targets(self, weights: bool = True):
+        """What the step needs from the target batch in self.y and the weights as they are before it starts.
+        weights=False: the discriminator's weight preparation (it advances the spectral norms' power iteration,
+        so it must run exactly once per discriminator update) has been done already; only the targets are new."""
+        B = self.B
+        if weights:
+            self.D.prepare()
+        if self.la_vgg:
+            self.V.forward(self.y, B, 2 * B, src0=0)
+        if self.la_dreal:
+            self.D.forward_images(self.d_in, 0, B)
 
     def _g_loss_backward(self, n: int):
         B, H, W, sc = self.B, self.H, self.W, self.sc
@@ -234,6 +276,25 @@ class TrainStep:
 
     def _body(self):
         B = self.B
+        if self.lookahead:         # the targets were prepared by the previous step (or _prime())
+            self._vgg_side, self._d_side, self._d_prepared = None, None, True
+            if not self.la_vgg:
+                self._vgg_side = self._fork(VGG_LANE, self.overlap_vgg)
+                with torch.cuda.stream(self._vgg_side):
+                    self.V.forward(self.y, B, 2 * B, src0=0)
+            side = None
+            if self.pre_dreal and not self.la_dreal:
+                side = self._fork(DBWD_LANE)
+                with torch.cuda.stream(side):
+                    self.D.forward_images(self.d_in, 0, B)
+            pred = self.G.forward(self.x)
+            if side is not None:
+                self._join(side)
+            assert pred.data_ptr() == self.d_in[B:].data_ptr()
+            yield from self._d_iteration(last=False)
+            yield from self._d_iteration(last=True)
+            self.gs.adam(self.lr)
+            return
         self._vgg_side = self._fork(VGG_LANE, self.overlap_vgg)      # target features beside the generator forward
         # ... and so do the first discriminator iteration's spectral norms and weight repacks (small kernels that need
         # only D's weights): 0.1 ms off the critical path
@@ -267,14 +328,49 @@ class TrainStep:
         for ev in self._body():
             self._handle(ev)
 
-    def step(self, x: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None):
+    def weights_changed(self):
+        """Tell the plan that the networks' weights were written from outside (a checkpoint restore): what a
+        look-ahead plan prepared for its next step with the old weights is discarded and done again.  (A checkpoint
+        saved after a look-ahead step holds spectral-norm vectors that are one power iteration ahead of the plain
+        plan's at the same point: that iteration belongs to the next step and has been run already.)"""
+        self._primed = self._d_ready = False
+
+    @staticmethod
+    def _key(t: torch.Tensor):
+        return (t.data_ptr(), t._version, tuple(t.shape))
+
+    def _prime(self):
+        """Look-ahead: prepare the targets in self.y now (first step, or a y that was not announced)."""
+        self._prep_targets(weights=not self._d_ready)
+        self._primed = self._d_ready = True
+
+    def step(self, x: Optional[torch.Tensor] = None, y: Optional[torch.Tensor] = None,
+             y_next: Optional[torch.Tensor] = None):
         """One training iteration on (x, y), fp32 (B,1,H,W) device tensors.  No host synchronisation; read
-        the losses afterwards with losses()."""
+        the losses afterwards with losses().  y_next (look-ahead plans only): the targets of the batch the NEXT
+        call will be given; that call finds its targets prepared if its y is this very tensor, unmodified, and
+        prepares them itself otherwise.  Without arguments the buffers self.x / self.y are used as they are (a
+        look-ahead plan then repeats the batch unless y_next announces another)."""
         if x is not None:
             self.x.copy_(x, non_blocking=True)
-            self.y.copy_(y, non_blocking=True)
+            announced = self.lookahead and self._primed and self._next_key is not None and self._key(y) == self._next_key
+            if not announced:            # (else self.y holds these targets already, prepared)
+                self.y.copy_(y, non_blocking=True)
+                self._primed = False
+        if self.lookahead:
+            if y_next is not None:
+                self.y_next.copy_(y_next, non_blocking=True)
+                self._next_key, self._ynext_is_y = self._key(y_next), False
+            elif x is not None or not self._ynext_is_y:      # nothing announced: the end of the step re-prepares this batch
+                self.y_next.copy_(self.y)
+                self._next_key, self._ynext_is_y = None, True
+            if self.use_graph and self.graphs is None:
+                self._capture()
+            if not self._primed:
+                self._prime()
         if not self.use_graph:
             self._run_eager()
+            self._warmed = True
         else:
             if self.graphs is None:
                 self._capture()
@@ -282,14 +378,21 @@ class TrainStep:
                 self.segment = i          # (where a stuck rank stands: read by watchdogs)
                 g.replay()
                 self._handle(ev)
-        self.steps_done += 1
+        self.steps_done += 1           # (look-ahead: self.y now holds the y_next buffer's batch, prepared)
 
     def _capture(self):
-        # one eager step first (loads every kernel, warms RCCL), then put the state back
-        snap = self._snapshot()
-        self._run_eager()
-        torch.cuda.synchronize()
-        self._restore(snap)
+        # one eager step first (loads every kernel, warms RCCL), then put the state back.  (Look-ahead: that step
+        # leaves targets prepared with weights that are then taken back, so the caller primes again; a re-capture -
+        # a new learning rate - of a plan whose kernels are loaded skips it and keeps what is prepared.)
+        if not (self.lookahead and self._warmed):
+            snap = self._snapshot()
+            if self.lookahead:
+                snap["y"] = self.y.clone()       # (the step ends by moving the y_next buffer into self.y)
+                self._prime()
+            self._run_eager()
+            torch.cuda.synchronize()
+            self._restore(snap)
+            self._primed, self._d_ready, self._warmed = False, False, True
         graphs = []
         gen = self._body()
         pool = None
@@ -325,6 +428,8 @@ class TrainStep:
             self.ds.b[k].copy_(v)
         for st, (m, v, n) in zip((self.gs, self.ds), s["adam"]):      # e.g. moments restored from a checkpoint
             st.adam_m.copy_(m); st.adam_v.copy_(v); st.adam_step.copy_(n)
+        if "y" in s:
+            self.y.copy_(s["y"])
 
     def losses(self) -> Dict[str, float]:
         """Host read of the last step's scalars (synchronises)."""

@@ -429,15 +429,15 @@ def test_inference_at_the_benchmark_size_vs_oracle():
             assert abs(a - b) <= 2e-2 * abs(b), (i, got[i][1], res[i][1])
 
 
-def weights_agree(a, b):
-    """Two runs of the same two steps.  The few float atomics left in the step (loss sums) differ in the last bit
+def weights_agree(a, b, steps=2):
+    """Two runs of the same `steps` steps.  The few float atomics left in the step (loss sums) differ in the last bit
     between runs, and Adam's first updates are lr * sign(gradient)-like: a weight whose gradient is almost zero can
     move the other way (up to 2 * lr per step apart: lr 1e-4 for G, 4e-4 for D).  So: nearly all weights agree
     tightly, and none is further apart than those sign flips allow."""
     for st_a, st_b, lr in ((a.gs, b.gs, 1e-4), (a.ds, b.ds, 4e-4)):
         d = (st_a.flat - st_b.flat).abs()
-        assert (d > 3 * lr).float().mean().item() <= 1e-4, (lr, d.max().item())
-        assert d.max().item() <= 2 * 2 * lr * 1.05, (lr, d.max().item())
+        assert (d > 1.5 * steps * lr).float().mean().item() <= 1e-4, (lr, d.max().item())
+        assert d.max().item() <= 2 * steps * lr * 1.05, (lr, d.max().item())
 
 
 def test_segmented_graphs_equal_single_graph(monkeypatch):
@@ -621,6 +621,46 @@ def test_optional_step_overlaps_give_the_same_step(monkeypatch):
         for k in a:
             assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
         weights_agree(plain, other)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_lookahead_steps_equal_plain_steps(monkeypatch, use_graph):
+    """lookahead=True: the target-only work of a step (VGG features of y, the first discriminator iteration's
+    weight preparation and its pass over the target half) is done for the NEXT batch at the end of the current
+    step.  The same kernels on the same data in another place: three steps over three different batches give the
+    losses and weights of the plain plan - with every next batch announced, with none announced (each step then
+    prepares its own targets), and with a wrong announcement (detected: the tensor passed is not the announced one)."""
+    B, H = 4, 64
+    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
+    batches = [tuple(t.to(DEV) for t in synth_batch(B, H, seed=60 + i)) for i in range(4)]
+    monkeypatch.setattr(engine, "BN_FOLD", False)        # fixed-order reductions: the runs must agree closely
+    plain = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=use_graph)
+    ahead = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=use_graph, lookahead=True)
+    blind = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=use_graph, lookahead=True)
+    wrong = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=use_graph, lookahead=True)
+    assert ahead.lookahead and ahead.pre_dreal and not plain.lookahead
+    for i in range(3):
+        x, y = batches[i]
+        plain.step(x, y)
+        ahead.step(x, y, y_next=batches[i + 1][1])
+        blind.step(x, y)
+        wrong.step(x, y, y_next=batches[(i + 2) % 4][1])
+        torch.cuda.synchronize()
+        a = plain.losses()
+        for name, other in (("ahead", ahead), ("blind", blind), ("wrong", wrong)):
+            b = other.losses()
+            for k in a:
+                assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (name, i, k, a[k], b[k])
+    for other in (ahead, blind, wrong):
+        weights_agree(plain, other, steps=3)
+    # replays without arguments repeat the batch: same as passing it again
+    x, y = batches[2]
+    plain.step(x, y); plain.step(x, y)
+    blind.step(); blind.step()
+    torch.cuda.synchronize()
+    a, b = plain.losses(), blind.losses()
+    for k in a:
+        assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
 
 
 def test_training_plan_with_the_one_launch_batchnorm_backward(monkeypatch):

@@ -14,7 +14,7 @@ x, y = synth_batch(128, 64, seed=1234)
 
 
 def timed(reps=60):
-    ts = TrainStep(g, d, vgg, 128, 64, 64, lr=1e-4)
+    ts = TrainStep(g, d, vgg, 128, 64, 64, lr=1e-4, lookahead=LOOKAHEAD)
     ts.x.copy_(x.cuda()); ts.y.copy_(y.cuda())
     for _ in range(5):
         ts.step()
@@ -30,9 +30,14 @@ def timed(reps=60):
     return ms, losses
 
 
+LOOKAHEAD = False
+
 if __name__ == "__main__":
     flips = {}
-    for a in sys.argv[1:]:
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    LOOKAHEAD = "--lookahead" in sys.argv           # both arms with the look-ahead plan
+    ab_lookahead = "--ab-lookahead" in sys.argv      # A: plain plan, B: look-ahead plan
+    for a in args:
         k, _, v = a.partition("=")
         flips[k] = type(getattr(engine, k))(int(v)) if v else (not getattr(engine, k))
     base = {k: getattr(engine, k) for k in flips}
@@ -41,6 +46,8 @@ if __name__ == "__main__":
         for name, vals in (("A", base), ("B", flips)):
             for k, v in vals.items():
                 setattr(engine, k, v)
+            if ab_lookahead:
+                LOOKAHEAD = name == "B"
             ms, losses = timed()
             res[name].append(ms)
             print(f"{name} {vals} {ms:.3f} ms  gen {losses['gen']:.4f}", flush=True)

@@ -14,7 +14,7 @@ x, y = synth_batch(128, 64, seed=1234)
 
 
 def timed(patch=None, reps=40):
-    ts = TrainStep(g, d, vgg, 128, 64, 64, lr=1e-4)
+    ts = TrainStep(g, d, vgg, 128, 64, 64, lr=1e-4, lookahead=not os.environ.get("RIED_NO_LOOKAHEAD"))
     ts.x.copy_(x.cuda()); ts.y.copy_(y.cuda())
     if patch:
         patch(ts)
