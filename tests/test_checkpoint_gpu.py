@@ -87,3 +87,28 @@ def test_restored_learning_rate_is_applied_and_recaptures(tmp_path):
     move_a = (a.gs.flat - before).abs().median().item()
     move_b = (b.gs.flat - before).abs().median().item()
     assert 0.8 < move_b / move_a < 1.25, (move_a, move_b)      # a step at the old rate would give 0.25
+
+
+def test_restore_into_a_lookahead_plan(tmp_path):
+    """A look-ahead plan has prepared its next step (target features, the discriminator's packed weights and its
+    pass over the targets) with the weights it had: restore() tells it, and the step after the restore is the step
+    the plain plan takes from the same checkpoint."""
+    B, H = 4, 64
+    gsd, dsd, vgg = synth_state(_spec("G"), 101), synth_state(_spec("D"), 202), synth_vgg()
+    x, y = (t.to(DEV) for t in synth_batch(B, H, seed=3))
+    a = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False)
+    a.step(x, y); a.step()
+    path = str(tmp_path / "ckpt.pth.tar")
+    C.save_checkpoint(path, a, epoch=1, total_iters=2)
+    b = TrainStep(synth_state(_spec("G"), 7), synth_state(_spec("D"), 8), vgg, B, H, H, lr=1e-4, use_graph=True,
+                  lookahead=True)
+    b.step(x, y)                       # captures; ends with the next step prepared from b's own weights
+    assert b._primed and b._d_ready
+    C.restore(b, C.load_checkpoint(path))
+    assert not b._primed and not b._d_ready
+    a.step(); b.step(x, y)
+    torch.cuda.synchronize()
+    la, lb = a.losses(), b.losses()
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 5e-3 * abs(la[k]) + 1e-6, (k, la[k], lb[k])
+    assert torch.allclose(a.gs.flat, b.gs.flat, rtol=0, atol=2.5e-4)
