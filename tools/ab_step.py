@@ -14,7 +14,7 @@ x, y = synth_batch(128, 64, seed=1234)
 
 
 def timed(reps=60):
-    ts = TrainStep(g, d, vgg, 128, 64, 64, lr=1e-4, lookahead=LOOKAHEAD)
+    ts = TrainStep(g, d, vgg, 128, 64, 64, lr=1e-4, lookahead=LOOKAHEAD, use_graph="--eager" not in sys.argv)
     ts.x.copy_(x.cuda()); ts.y.copy_(y.cuda())
     for _ in range(5):
         ts.step()
