@@ -12,7 +12,7 @@ import re
 from typing import Dict, List, Tuple
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libried_gan.so")
+LIB_PATH = os.environ.get("RIED_LIB_PATH") or os.path.join(_PKG, "libried_gan.so")     # (another build, for A/B runs)
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "ried_gan.h")
 
 _CTYPES = {

@@ -569,6 +569,13 @@ __device__ __forceinline__ void bn_bwd_apply_body(
   if (!w.active) return;
   const int c = w.c;
   const float invn = 1.f / (float)npix;
+  // the first two pixels of the walk are fetched together with the sums, not after them (see bn_apply_train_body)
+  u32x4 pg[2], px[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const long long p = w.p + k * w.step;
+    if (p < npix) { pg[k] = ld8(dy + p * lddy + c); px[k] = ld8(x + p * ldx + c); }
+  }
   float a[8], b[8], mean[8], istd[8], m1[8], m2[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -591,8 +598,24 @@ __device__ __forceinline__ void bn_bwd_apply_body(
   }
 #pragma unroll
   for (int q = 0; q < 8; ++q) { m1[q] *= invn; m2[q] *= invn; }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const long long p = w.p + k * w.step;
+    if (p < npix) {
+      float g[8], xv[8];
+      unpack8(pg[k], g);
+      unpack8(px[k], xv);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float d = xv[q] - mean[q];
+        float gg = bn_act_grad(d * a[q] + b[q], g[q], relu);
+        g[q] = a[q] * (gg - m1[q] - d * istd[q] * m2[q]);
+      }
+      st8(dx + p * lddx + c, pack8(g));
+    }
+  }
 #pragma unroll 2
-  for (long long p = w.p; p < npix; p += w.step) {
+  for (long long p = w.p + 2 * w.step; p < npix; p += w.step) {
     float g[8], xv[8];
     unpack8(ld8(dy + p * lddy + c), g);
     unpack8(ld8(x + p * ldx + c), xv);
@@ -985,6 +1008,17 @@ __device__ __forceinline__ void bn_apply_train_body(
   __shared__ float sums[2][BN_SLICE];
   __shared__ float ab[2][BN_SLICE];
   SliceWalk w(C);
+  // The first two pixels of the thread's walk are fetched before the statistics are (a dependent round trip to
+  // memory otherwise: most of this kernel's time on the small layers, which are a single pass).
+  u32x4 px[2], po[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const long long p = w.p + k * w.step;
+    if (w.active && p < npix) {
+      px[k] = ld8(x + p * ldx + w.c);
+      if (accumulate) po[k] = ld8(y + p * ldy + w.c);
+    }
+  }
   slice_row_sums(stats, nrows, C, ldstat, w.c0, w.SW, lds, &sums[0][0]);
   if (threadIdx.x < w.SW && w.c0 + threadIdx.x < C) {
     const int c = w.c0 + threadIdx.x;
@@ -1012,8 +1046,23 @@ __device__ __forceinline__ void bn_apply_train_body(
   float a[8], b[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) { a[q] = ab[0][w.cl * 8 + q]; b[q] = ab[1][w.cl * 8 + q]; }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const long long p = w.p + k * w.step;
+    if (p < npix) {
+      float f[8], o[8];
+      unpack8(px[k], f);
+      if (accumulate) unpack8(po[k], o);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float v = bn_act(f[q] * a[q] + b[q], relu);
+        f[q] = accumulate ? v + o[q] : v;
+      }
+      st8(y + p * ldy + c, pack8(f));
+    }
+  }
 #pragma unroll 2
-  for (long long p = w.p; p < npix; p += w.step) {
+  for (long long p = w.p + 2 * w.step; p < npix; p += w.step) {
     float f[8], o[8];
     unpack8(ld8(x + p * ldx + c), f);
     if (accumulate) unpack8(ld8(y + p * ldy + c), o);
