@@ -174,23 +174,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 //   Dq[i] = sum_c dO[i][c] O[i][c];  P = exp(energy - lse);  dP = dO v^T;  dS = P (dP - Dq)
 //   dv = P^T dO,  dk = dS^T q,  dq = dS k;  dgamma[0] += sum dout * O
 // ---------------------------------------------------------------------------------------------------------------
-template <int N, int D, int C, bool VREG>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, long long ld,
-                                                       bf16_t* __restrict__ dqkv, long long ldg,
-                                                       const bf16_t* __restrict__ dout, long long lddo,
-                                                       const bf16_t* __restrict__ O, long long ldO,
-                                                       const float* __restrict__ lse, const float* __restrict__ gamma,
-                                                       float* __restrict__ dgamma) {
+template <int N, int D, int C, bool VREG, int NG>
+__global__ __launch_bounds__(256 * NG) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, long long ld,
+                                                            bf16_t* __restrict__ dqkv, long long ldg,
+                                                            const bf16_t* __restrict__ dout, long long lddo,
+                                                            const bf16_t* __restrict__ O, long long ldO,
+                                                            const float* __restrict__ lse,
+                                                            const float* __restrict__ gamma,
+                                                            float* __restrict__ dgamma) {
+  // NG groups of four waves: group r takes key blocks r, r + NG, ... while all groups share the staged query block
+  // (two waves per SIMD instead of one, half as many passes over the query blocks); the groups' partial dq are
+  // added up through LDS at the end.
+  constexpr int NT = 256 * NG;
   constexpr int NB = N / 64, KH = D / 32, CK = C / 32, CT = C / 16, ET = D / 16, PQ = D + 8, PS = 72;
+  static_assert(NB % NG == 0 && (64 * C / 8) % NT == 0, "key blocks per group, staging loads per thread");
+  static_assert(NG == 1 || NB * ET * 4 * 64 * 16 <= 64 * C * 2, "the dq exchange reuses the dout tile");
   extern __shared__ __align__(16) unsigned char attn_smem[];
   bf16_t* dOl = reinterpret_cast<bf16_t*>(attn_smem);        // [64 queries][C], swizzled
   bf16_t* Ql = dOl + 64 * C;                                  // [64 queries][PQ]
-  bf16_t* Kl = Ql + 64 * PQ;                                  // [64 keys][PQ]
-  bf16_t* dSl = Kl + 64 * PQ;                                 // [64 keys][PS] (queries along the row)
-  float* Dq = reinterpret_cast<float*>(dSl + 64 * PS);        // [N]
+  bf16_t* Kl0 = Ql + 64 * PQ;                                 // [NG][64 keys][PQ]
+  bf16_t* dSl0 = Kl0 + NG * 64 * PQ;                          // [NG][64 keys][PS] (queries along the row)
+  float* Dq = reinterpret_cast<float*>(dSl0 + NG * 64 * PS);  // [N]
   float* lsel = Dq + N;                                       // [N]
-  float* red = lsel + N;                                      // [4]
+  float* red = lsel + N;                                      // [4 * NG]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l = lane & 15;
+  const int grp = wave >> 2, w4 = wave & 3, gtid = tid & 255;
+  bf16_t* Kl = Kl0 + grp * 64 * PQ;
+  bf16_t* dSl = dSl0 + grp * 64 * PS;
   const long long img = blockIdx.x;
   const bf16_t* base = qkv + img * N * ld;
   bf16_t* gbase = dqkv + img * N * ldg;
@@ -199,7 +209,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
   const float gam = gamma[0];
   // Dq (without gamma) and the block's share of dgamma
   {
-    constexpr int LPR = C / 8, RPP = 256 / LPR;
+    constexpr int LPR = C / 8, RPP = NT / LPR;
     const int c8 = (tid % LPR) * 8;
     float tot = 0.f;
     for (int q = tid / LPR; q < N; q += RPP) {
@@ -213,12 +223,17 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
       for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
       if ((tid % LPR) == 0) Dq[q] = s;
     }
-    for (int q = tid; q < N; q += 256) lsel[q] = lse[img * N + q];
+    for (int q = tid; q < N; q += NT) lsel[q] = lse[img * N + q];
     if (dgamma) {
       tot = wave_sum(tot);
       if (lane == 0) red[wave] = tot;
       __syncthreads();
-      if (tid == 0) atomicAdd(dgamma, red[0] + red[1] + red[2] + red[3]);
+      if (tid == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4 * NG; ++k) t += red[k];
+        atomicAdd(dgamma, t);
+      }
     }
   }
   f32x4 dQacc[NB][ET];                                        // D[i = e][j = query 16w + l] of query block ib
@@ -227,8 +242,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int et = 0; et < ET; ++et) dQacc[ib][et] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int jb = 0; jb < NB; ++jb) {
-    const bf16_t* krow = base + (long long)(jb * 64 + wave * 16 + l) * ld;        // this lane's key (B operands)
+  for (int jb2 = 0; jb2 < NB / NG; ++jb2) {
+    const int jb = jb2 * NG + grp;
+    const bf16_t* krow = base + (long long)(jb * 64 + w4 * 16 + l) * ld;          // this lane's key (B operands)
     bf16x8_t fk[KH];
 #pragma unroll
     for (int h = 0; h < KH; ++h) fk[h] = ld_frag(krow + D + h * 32 + 8 * g);
@@ -243,23 +259,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
 #pragma unroll
     for (int et = 0; et < ET; ++et) dKacc[et] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();                                          // the previous key block's last dq pass has read Kl
-    for (int idx = tid; idx < 64 * D / 8; idx += 256) {
+    for (int idx = gtid; idx < 64 * D / 8; idx += 256) {      // every group its own key block
       const int r = idx / (D / 8), c8 = (idx % (D / 8)) * 8;
       *reinterpret_cast<u32x4*>(Kl + r * PQ + c8) =
           *reinterpret_cast<const u32x4*>(base + (long long)(jb * 64 + r) * ld + D + c8);
     }
     // The next query block's dout and q rows travel global -> registers while the current block is computed.
-    constexpr int NDO = C / 32, NQ = (64 * D / 8 + 255) / 256;
+    constexpr int NDO = 64 * C / 8 / NT, NQ = (64 * D / 8 + NT - 1) / NT;
     u32x4 pdo[NDO], pq[NQ];
     auto fetch = [&](int ib) {
 #pragma unroll
       for (int u = 0; u < NDO; ++u) {
-        const int idx = tid + 256 * u, r = idx / (C / 8), c8 = (idx % (C / 8)) * 8;
+        const int idx = tid + NT * u, r = idx / (C / 8), c8 = (idx % (C / 8)) * 8;
         pdo[u] = *reinterpret_cast<const u32x4*>(dob + (long long)(ib * 64 + r) * lddo + c8);
       }
 #pragma unroll
       for (int u = 0; u < NQ; ++u) {
-        const int idx = tid + 256 * u, r = idx / (D / 8), c8 = (idx % (D / 8)) * 8;
+        const int idx = tid + NT * u, r = idx / (D / 8), c8 = (idx % (D / 8)) * 8;
         if (idx < 64 * D / 8) pq[u] = *reinterpret_cast<const u32x4*>(base + (long long)(ib * 64 + r) * ld + c8);
       }
     };
@@ -269,16 +285,20 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
       // stage this query block: dout rows (swizzled) and q rows
 #pragma unroll
       for (int u = 0; u < NDO; ++u) {
-        const int idx = tid + 256 * u, r = idx / (C / 8), c8 = (idx % (C / 8)) * 8;
+        const int idx = tid + NT * u, r = idx / (C / 8), c8 = (idx % (C / 8)) * 8;
         *reinterpret_cast<u32x4*>(dOl + r * C + (c8 ^ attn_swz(r))) = pdo[u];
       }
 #pragma unroll
       for (int u = 0; u < NQ; ++u) {
-        const int idx = tid + 256 * u, r = idx / (D / 8), c8 = (idx % (D / 8)) * 8;
+        const int idx = tid + NT * u, r = idx / (D / 8), c8 = (idx % (D / 8)) * 8;
         if (idx < 64 * D / 8) *reinterpret_cast<u32x4*>(Ql + r * PQ + c8) = pq[u];
       }
       __syncthreads();
       if (ib + 1 < NB) fetch(ib + 1);
+      // (LDS addresses recomputed per query block: hoisted out of the unrolled loops they cost ~100 registers)
+      int lane_v = lane;
+      asm volatile("" : "+v"(lane_v));
+      const int l = lane_v & 15, g = lane_v >> 4;
       // energy and dP tiles: D[i = query 16t + 4g + r][j = key]
       f32x4 s[4], dp[4];
 #pragma unroll
@@ -311,7 +331,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
           s[t][r] = p;
         }
         // dS^T image: row = this lane's key, four consecutive queries
-        *reinterpret_cast<u32x2*>(dSl + (wave * 16 + l) * PS + q) =
+        *reinterpret_cast<u32x2*>(dSl + (w4 * 16 + l) * PS + q) =
             u32x2{pack2bf(dp[t][0], dp[t][1]), pack2bf(dp[t][2], dp[t][3])};
       }
       // contractions over the 64 queries: dv^T and dk^T for this wave's keys
@@ -321,23 +341,23 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
         const bf16x8_t bs = pack_pair(dp[2 * h], dp[2 * h + 1]);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct)
-          dVacc[ct] = mfma16(tr_frag<true, true>(dOl, C, 32 * h, 16 * ct, lane), bp, dVacc[ct]);
+          dVacc[ct] = mfma16(tr_frag<true, true>(dOl, C, 32 * h, 16 * ct, lane_v), bp, dVacc[ct]);
 #pragma unroll
         for (int et = 0; et < ET; ++et)
-          dKacc[et] = mfma16(tr_frag<false, true>(Ql, PQ, 32 * h, 16 * et, lane), bs, dKacc[et]);
+          dKacc[et] = mfma16(tr_frag<false, true>(Ql, PQ, 32 * h, 16 * et, lane_v), bs, dKacc[et]);
       }
       __syncthreads();
       // dq^T for this wave's queries: D[i = e][j = query] = sum_key k[key][e] dS[query][key]; both operands are
       // [key][.] images read through the transposing load
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const bf16x8_t b = tr_frag<false, false>(dSl, PS, 32 * h, 16 * wave, lane);
+        const bf16x8_t b = tr_frag<false, false>(dSl, PS, 32 * h, 16 * w4, lane_v);
 #pragma unroll
         for (int et = 0; et < ET; ++et)
-          dQacc[ib][et] = mfma16(tr_frag<false, false>(Kl, PQ, 32 * h, 16 * et, lane), b, dQacc[ib][et]);
+          dQacc[ib][et] = mfma16(tr_frag<false, false>(Kl, PQ, 32 * h, 16 * et, lane_v), b, dQacc[ib][et]);
       }
     }
-    bf16_t* grow = gbase + (long long)(jb * 64 + wave * 16 + l) * ldg;
+    bf16_t* grow = gbase + (long long)(jb * 64 + w4 * 16 + l) * ldg;
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct)
       *reinterpret_cast<u32x2*>(grow + 2 * D + 16 * ct + 4 * g) =
@@ -347,9 +367,29 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const bf16_t* __restrict_
       *reinterpret_cast<u32x2*>(grow + D + 16 * et + 4 * g) =
           u32x2{pack2bf(dKacc[et][0], dKacc[et][1]), pack2bf(dKacc[et][2], dKacc[et][3])};
   }
+  if constexpr (NG > 1) {            // the other groups' dq partial sums, through the (now dead) dout tile
+    f32x4* xch = reinterpret_cast<f32x4*>(attn_smem);
+    static_assert(NG == 2, "one exchange step");
+    if (grp == 1) {
+#pragma unroll
+      for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+        for (int et = 0; et < ET; ++et) xch[((ib * ET + et) * 4 + w4) * 64 + lane] = dQacc[ib][et];
+    }
+    __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+      for (int et = 0; et < ET; ++et) {
+        const f32x4 o = xch[((ib * ET + et) * 4 + w4) * 64 + lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dQacc[ib][et][r] += o[r];
+      }
+  }
 #pragma unroll
   for (int ib = 0; ib < NB; ++ib) {
-    bf16_t* grow = gbase + (long long)(ib * 64 + wave * 16 + l) * ldg;
+    bf16_t* grow = gbase + (long long)(ib * 64 + w4 * 16 + l) * ldg;
 #pragma unroll
     for (int et = 0; et < ET; ++et)
       *reinterpret_cast<u32x2*>(grow + 16 * et + 4 * g) =
@@ -404,9 +444,9 @@ extern "C" int ried_attn_fwd(const void* qkv, long long ld, const void* x, long 
   return RIED_OK;
 }
 
-template <int N, int D, int C>
+template <int N, int D, int C, int NG>
 static constexpr size_t attn_bwd_lds() {
-  return (size_t)(64 * C + 2 * 64 * (D + 8) + 64 * 72) * sizeof(bf16_t) + (2 * N + 4) * sizeof(float);
+  return (size_t)(64 * C + (1 + NG) * 64 * (D + 8) + NG * 64 * 72) * sizeof(bf16_t) + (2 * N + 4 * NG) * sizeof(float);
 }
 
 extern "C" int ried_attn_bwd(const void* qkv, long long ld, void* dqkv, long long ldg, const void* dout, long long lddo,
@@ -416,15 +456,20 @@ extern "C" int ried_attn_bwd(const void* qkv, long long ld, void* dqkv, long lon
   if (rc) return rc;
   RIED_CHECK_ARG(aligned_view(dqkv, ldg, 2 * d + C) && aligned_view(dout, lddo, C) && aligned_view(O, ldO, C) && lse && gamma,
                  "ried_attn_bwd: bad view");
-  static int raised = 0;
-  if (n == 256) {
-    auto k = attn_bwd_kernel<256, 32, 256, true>;
-    const size_t sh = attn_bwd_lds<256, 32, 256>();
-    hipLaunchKernelGGL(k, dim3(nimg), dim3(256), sh, stream, (const bf16_t*)qkv, ld, (bf16_t*)dqkv, ldg,
+  static int raised = 0, raised2 = 0;
+  if (n == 256) {            // two groups of four waves: two key blocks at a time
+    auto k = attn_bwd_kernel<256, 32, 256, false, 2>;
+    const size_t sh = attn_bwd_lds<256, 32, 256, 2>();
+    if (!raised2) {
+      rc = raise_lds(k, sh, "ried_attn_bwd");
+      if (rc) return rc;
+      raised2 = 1;
+    }
+    hipLaunchKernelGGL(k, dim3(nimg), dim3(512), sh, stream, (const bf16_t*)qkv, ld, (bf16_t*)dqkv, ldg,
                        (const bf16_t*)dout, lddo, (const bf16_t*)O, ldO, lse, gamma, dgamma);
   } else {
-    auto k = attn_bwd_kernel<64, 64, 512, false>;
-    const size_t sh = attn_bwd_lds<64, 64, 512>();
+    auto k = attn_bwd_kernel<64, 64, 512, false, 1>;
+    const size_t sh = attn_bwd_lds<64, 64, 512, 1>();
     if (!raised) {
       rc = raise_lds(k, sh, "ried_attn_bwd");
       if (rc) return rc;
