@@ -174,7 +174,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
 //   Dq[i] = sum_c dO[i][c] O[i][c];  P = exp(energy - lse);  dP = dO v^T;  dS = P (dP - Dq)
 //   dv = P^T dO,  dk = dS^T q,  dq = dS k;  dgamma[0] += sum dout * O
 // ---------------------------------------------------------------------------------------------------------------
-template <int N, int D, int C, bool VREG, int NG>
+// VMODE: where a wave keeps the v fragments of its 16 keys while it walks the query blocks - 0 nowhere (fetched
+// again for every query block), 1 registers, 2 its own slice of LDS (lane-linear: written and read by the same
+// lanes, no barrier, no bank conflict).
+template <int N, int D, int C, int VMODE, int NG>
 __global__ __launch_bounds__(256 * NG) void attn_bwd_kernel(const bf16_t* __restrict__ qkv, long long ld,
                                                             bf16_t* __restrict__ dqkv, long long ldg,
                                                             const bf16_t* __restrict__ dout, long long lddo,
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(256 * NG) void attn_bwd_kernel(const bf16_t* __rest
   float* Dq = reinterpret_cast<float*>(dSl0 + NG * 64 * PS);  // [N]
   float* lsel = Dq + N;                                       // [N]
   float* red = lsel + N;                                      // [4 * NG]
+  u32x4* vkeep = reinterpret_cast<u32x4*>(red + 4 * NG);      // VMODE 2: [4 * NG waves][C / 32][64 lanes] fragments
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l = lane & 15;
   const int grp = wave >> 2, w4 = wave & 3, gtid = tid & 255;
   bf16_t* Kl = Kl0 + grp * 64 * PQ;
@@ -248,10 +252,15 @@ __global__ __launch_bounds__(256 * NG) void attn_bwd_kernel(const bf16_t* __rest
     bf16x8_t fk[KH];
 #pragma unroll
     for (int h = 0; h < KH; ++h) fk[h] = ld_frag(krow + D + h * 32 + 8 * g);
-    bf16x8_t fv[VREG ? CK : 1];
-    if constexpr (VREG) {
+    bf16x8_t fv[VMODE == 1 ? CK : 1];
+    if constexpr (VMODE == 1) {
 #pragma unroll
       for (int s = 0; s < CK; ++s) fv[s] = ld_frag(krow + 2 * D + s * 32 + 8 * g);
+    }
+    if constexpr (VMODE == 2) {
+#pragma unroll
+      for (int s = 0; s < CK; ++s)
+        vkeep[(wave * CK + s) * 64 + lane] = *reinterpret_cast<const u32x4*>(krow + 2 * D + s * 32 + 8 * g);
     }
     f32x4 dVacc[CT], dKacc[ET];                               // D[i = channel | e][j = key 16w + l]
 #pragma unroll
@@ -311,7 +320,8 @@ __global__ __launch_bounds__(256 * NG) void attn_bwd_kernel(const bf16_t* __rest
 #pragma unroll
       for (int k = 0; k < CK; ++k) {
         bf16x8_t bv;
-        if constexpr (VREG) bv = fv[k];
+        if constexpr (VMODE == 1) bv = fv[k];
+        else if constexpr (VMODE == 2) bv = __builtin_bit_cast(bf16x8_t, vkeep[(wave * CK + k) * 64 + lane]);
         else bv = ld_frag(krow + 2 * D + k * 32 + 8 * g);
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -444,9 +454,10 @@ extern "C" int ried_attn_fwd(const void* qkv, long long ld, const void* x, long 
   return RIED_OK;
 }
 
-template <int N, int D, int C, int NG>
+template <int N, int D, int C, int NG, int VMODE>
 static constexpr size_t attn_bwd_lds() {
-  return (size_t)(64 * C + (1 + NG) * 64 * (D + 8) + NG * 64 * 72) * sizeof(bf16_t) + (2 * N + 4 * NG) * sizeof(float);
+  return (size_t)(64 * C + (1 + NG) * 64 * (D + 8) + NG * 64 * 72) * sizeof(bf16_t) + (2 * N + 4 * NG) * sizeof(float) +
+         (VMODE == 2 ? (size_t)4 * NG * (C / 32) * 64 * 16 : 0);
 }
 
 extern "C" int ried_attn_bwd(const void* qkv, long long ld, void* dqkv, long long ldg, const void* dout, long long lddo,
@@ -458,8 +469,8 @@ extern "C" int ried_attn_bwd(const void* qkv, long long ld, void* dqkv, long lon
                  "ried_attn_bwd: bad view");
   static int raised = 0, raised2 = 0;
   if (n == 256) {            // two groups of four waves: two key blocks at a time
-    auto k = attn_bwd_kernel<256, 32, 256, false, 2>;
-    const size_t sh = attn_bwd_lds<256, 32, 256, 2>();
+    auto k = attn_bwd_kernel<256, 32, 256, 2, 2>;
+    const size_t sh = attn_bwd_lds<256, 32, 256, 2, 2>();
     if (!raised2) {
       rc = raise_lds(k, sh, "ried_attn_bwd");
       if (rc) return rc;
@@ -468,8 +479,8 @@ extern "C" int ried_attn_bwd(const void* qkv, long long ld, void* dqkv, long lon
     hipLaunchKernelGGL(k, dim3(nimg), dim3(512), sh, stream, (const bf16_t*)qkv, ld, (bf16_t*)dqkv, ldg,
                        (const bf16_t*)dout, lddo, (const bf16_t*)O, ldO, lse, gamma, dgamma);
   } else {
-    auto k = attn_bwd_kernel<64, 64, 512, false, 1>;
-    const size_t sh = attn_bwd_lds<64, 64, 512, 1>();
+    auto k = attn_bwd_kernel<64, 64, 512, 0, 1>;
+    const size_t sh = attn_bwd_lds<64, 64, 512, 1, 0>();
     if (!raised) {
       rc = raise_lds(k, sh, "ried_attn_bwd");
       if (rc) return rc;
