@@ -58,8 +58,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const bf16_t* __restrict_
   extern __shared__ __align__(16) unsigned char attn_smem[];
   bf16_t* vl = reinterpret_cast<bf16_t*>(attn_smem);          // [64 keys][CB], swizzled
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, l = lane & 15;
-  const long long img = blockIdx.y;
-  const int q0 = blockIdx.x * 64 + wave * 16, c0 = blockIdx.z * CB;
+  // Workgroups go to the XCDs round-robin by their linear index, and every query block of an image reads all of that
+  // image's v: the blocks are renumbered so that an image's query blocks run on ONE XCD (its v is fetched into one
+  // L2 instead of N / 64 of them).  Needs whole rounds of 8 images; otherwise the plain numbering.
+  int qb = blockIdx.x;
+  long long img = blockIdx.y;
+  if ((gridDim.y & 7) == 0) {
+    const int id = blockIdx.x + gridDim.x * blockIdx.y, xcd = id & 7, slot = id >> 3;
+    img = (long long)(slot / (int)gridDim.x) * 8 + xcd;
+    qb = slot % (int)gridDim.x;
+  }
+  const int q0 = qb * 64 + wave * 16, c0 = blockIdx.z * CB;
   const bf16_t* base = qkv + img * N * ld;
   // energy^T tiles: D[i = key][j = query] with A = k rows, B = q rows
   bf16x8_t fq[KH];
