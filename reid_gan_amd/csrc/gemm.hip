@@ -1674,8 +1674,19 @@ __device__ __forceinline__ void wgrad_glds_body(const GemmParams& P, int bx, int
 template <int BM, int BN, int NST>
 __global__ __launch_bounds__(256) void wgrad_glds_kernel(const GemmParams P) {
   __shared__ __attribute__((aligned(1024))) char smem[NST * BK * (BM + BN) * 2];
-  wgrad_glds_body<BM, BN, NST>(P, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x / P.tiles_m,
-                               gridDim.x * gridDim.y * gridDim.z, smem);
+  // Workgroups go to the XCDs round-robin by their linear index (tile fastest, then tap, then k split), while the
+  // blocks that read the same pixels are those of one k split: renumbered so that a split's blocks run on ONE XCD
+  // (its pixels are fetched into one L2, not eight).  The splits beyond the last whole round of 8 keep their numbers.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  const int per = gridDim.x * gridDim.y, whole = (int)gridDim.z & ~7;
+  const int id = bx + (int)gridDim.x * (by + (int)gridDim.y * bz);
+  if (id < per * whole) {
+    const int xcd = id & 7, slot = id >> 3, w = slot % per;
+    bz = (slot / per) * 8 + xcd;
+    bx = w % (int)gridDim.x;
+    by = w / (int)gridDim.x;
+  }
+  wgrad_glds_body<BM, BN, NST>(P, bx, by, bz, gridDim.x / P.tiles_m, gridDim.x * gridDim.y * gridDim.z, smem);
 }
 
 template <int BM, int BN, int NST>
