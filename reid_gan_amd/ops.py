@@ -143,7 +143,7 @@ class WgradJobs:
         lib.ried_conv2d_wgrad_make_job(rec.ctypes.data, g.ptr, g.ld, g.C, g.N, g.H, g.W, p.ptr, p.ld, p.C, p.H, p.W,
                                        kh, kw, sh, sw, ph, pw, slab_ptr, splitk, tile.ctypes.data, nb.ctypes.data)
         recs, counts = self.groups.setdefault((int(tile[0]), int(tile[1])), ([], []))
-        recs.append(rec); counts.append(int(nb[0]))
+        recs.append(rec); counts.append((int(nb[0]), kh * kw * (int(nb[0]) // (kh * kw * splitk))))
         self.flops += 2.0 * p.npix * p.C * g.C * kh * kw
         key = (int(tile[0]), int(tile[1]))
         self.group_flops[key] = self.group_flops.get(key, 0.0) + 2.0 * p.npix * p.C * g.C * kh * kw
@@ -155,8 +155,37 @@ class WgradJobs:
         self.dev = []
         for (bm, bn), (recs, counts) in sorted(self.groups.items()):
             jobs = torch.from_numpy(np.concatenate(recs)).to(device)
-            m = np.asarray([(j, b) for j, c in enumerate(counts) for b in range(c)], dtype=np.int32).reshape(-1)
-            self.dev.append((bm, bn, jobs, torch.from_numpy(m).to(device), sum(counts)))
+            m = self._xcd_order([(j, c, per) for j, (c, per) in enumerate(counts)])
+            self.dev.append((bm, bn, jobs, torch.from_numpy(m).to(device), sum(c for c, _ in counts)))
+
+    @staticmethod
+    def _xcd_order(jobs):
+        """map[pos] = (job, block of that job) for one launch.  Workgroups go to the 8 XCDs round-robin by their
+        position; the blocks of a job that read the same pixels are those of one k split (`per` consecutive blocks),
+        so a split's blocks are dealt to positions of one residue mod 8 as far as the counts allow (its pixels are
+        then fetched into one L2 instead of eight).  Any permutation is valid: only the speed depends on it."""
+        import numpy as np
+        import os
+        if os.environ.get("RIED_NO_XCD_MAP"):              # A/B switch: blocks in their own order
+            return np.asarray([(j, b) for j, c, _ in jobs for b in range(c)], dtype=np.int32).reshape(-1)
+        out, pos0 = [], 0
+        for j, count, per in jobs:
+            pos = np.arange(pos0, pos0 + count)
+            blocks = np.arange(count)
+            cls = (blocks // per) % 8                      # the XCD a split would like
+            m = np.full(count, -1, dtype=np.int64)
+            left_b, left_p = [], []
+            for c in range(8):
+                pc, bc = np.nonzero(pos % 8 == c)[0], blocks[cls == c]
+                n = min(len(pc), len(bc))
+                m[pc[:n]] = bc[:n]
+                left_p.append(pc[n:]); left_b.append(bc[n:])
+            lp, lb = np.concatenate(left_p), np.concatenate(left_b)
+            m[lp] = lb
+            assert sorted(m.tolist()) == list(range(count))
+            out.append(np.stack([np.full(count, j, dtype=np.int64), m], axis=1))
+            pos0 += count
+        return np.concatenate(out).astype(np.int32).reshape(-1)
 
     def launch(self, around=None):
         """around(bm, bn, fn): reporting hook that runs fn (one tile shape's launch) between its own timers."""
