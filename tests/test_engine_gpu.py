@@ -363,7 +363,10 @@ def test_train_step_at_the_benchmark_batch():
     with emu():
         ref = O.train_step(O.TrainState(gsd, dsd, vgg, lr=1e-4), x, y, want_grads=True)
     f32 = O.train_step(O.TrainState(gsd, dsd, vgg, lr=1e-4), x, y, want_grads=True)
-    ts = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
+    # the plan bench.py times on one GPU: captured graph, look-ahead (the target-only work in front of this first
+    # step, and again - for the same batch - at its end)
+    ts = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True, lookahead=True)
+    assert ts.lookahead and ts.pre_dreal
     ts.step(x.to(DEV), y.to(DEV))
     got = ts.losses()
     for k in ("dloss1", "dloss2", "gloss", "vgg", "dssim", "gen"):
