@@ -27,6 +27,11 @@ typedef struct ihipStream_t* ried_stream_t; /* == hipStream_t */
 const char* ried_last_error(void);
 int ried_abi_version(void);
 int ried_device_cus(void);
+/* Diagnostics, no counterpart in the reference: on SIGABRT / SIGSEGV / SIGBUS / SIGFPE / SIGILL write the native
+ * frames of the thread that received the signal (glibc backtrace) to stderr - or to extra_fd when it is >= 0 - and to
+ * the file log_path_host (NULL: none; opened for append at installation), then pass the signal on to the handler
+ * that was installed before (Python's faulthandler, or the default action).  Idempotent. */
+int ried_install_crash_backtrace(const char* log_path_host, int extra_fd);
 
 /* ---- implicit-GEMM convolutions (bf16 in, fp32 accumulate, MFMA) -------------------------------
  * Conv2d forward (transposed = 0): replaces nn.Conv2d at src/rinet.py:186 (BasicConv2d), :137 (SNConv2d),
@@ -213,6 +218,17 @@ int ried_bn_backward(const void* dy, long long lddy, const void* x, long long ld
                      long long npix, int C, const float* save, const float* gamma, const float* beta, int relu,
                      float* scratch, float* dgamma, float* dbeta, int accumulate, unsigned* counter, float* folded,
                      ried_stream_t stream);
+/* The two launches of the folded form of ried_bn_backward as calls of their own, for synchronised BatchNorm under
+ * data parallelism (the option torch.nn.SyncBatchNorm would add to the DataParallel the reference leaves commented
+ * out at src/train.py:95-96): reduce adds the sums of g and g * x-hat into the ZEROED rows `folded`; the caller
+ * averages `folded` over the ranks; apply writes dx from the rows (it divides by npix, so rank-averaged local sums
+ * give the global-batch formula) and, when dgamma / dbeta are not NULL, the rows' totals as parameter gradients. */
+int ried_bn_backward_reduce(const void* dy, long long lddy, const void* x, long long ldx, long long npix, int C,
+                            const float* save, const float* gamma, const float* beta, int relu, float* folded,
+                            ried_stream_t stream);
+int ried_bn_backward_apply(const void* dy, long long lddy, const void* x, long long ldx, void* dx, long long lddx,
+                           long long npix, int C, const float* save, const float* gamma, const float* beta, int relu,
+                           const float* folded, float* dgamma, float* dbeta, int accumulate, ried_stream_t stream);
 long long ried_bn_backward_scratch_floats(int C);
 long long ried_bn_backward_folded_floats(int C);
 /* 1 when njobs layers of npix pixels and at most maxC channels each can take the one-launch form (0: too large). */

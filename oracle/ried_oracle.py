@@ -532,7 +532,8 @@ class TrainState:
         self.d_step = 0
 
 
-def train_step(st: TrainState, x: Tensor, y: Tensor, want_grads: bool = False) -> Dict[str, object]:
+def train_step(st: TrainState, x: Tensor, y: Tensor, want_grads: bool = False, fresh_d: bool = False,
+               shards: int = 1) -> Dict[str, object]:
     """One iteration of train.py:153-177 under the one well-defined reading of it:
 
       pred = G(x)                                   (train.py:153)
@@ -546,17 +547,54 @@ def train_step(st: TrainState, x: Tensor, y: Tensor, want_grads: bool = False) -
     update between forward and backward); the forward values below are the
     script's.  Work whose result the script discards (D-loss gradient into G,
     VGG weight gradients) is not computed.
+
+    fresh_d: the alternative the script's author left commented out at
+    train.py:171 (`D_gen = Dnet(pred)`): pred_neg for the generator loss comes
+    from a new training-mode forward of the discriminator on pred after BOTH
+    of its updates (so the spectral norms run one more power iteration), and
+    the G gradient goes through that discriminator.
+
+    shards > 1: the data-parallel form of the same step, W equal shards of the
+    batch on W replicas.  The generator's train-mode BatchNorm sees one shard
+    at a time (per-replica statistics: what the nn.DataParallel commented out
+    at train.py:95-96 would do); nothing else couples the samples of a batch
+    (the discriminator has no BatchNorm, attention is per image), and every
+    loss is a mean over the global batch - DLoss / GLoss of the GLOBAL means
+    (loss.py:141-142,154-155) - so the gradients below equal the average over
+    replicas of the per-replica gradients.  Running statistics: shard 0's.
     """
     gp = {k: (v.clone().requires_grad_(True) if trainable(k) else v.clone()) for k, v in st.g.items()}
     PG = Params(gp)
-    pred = rigan_forward(PG, x, training=True)
+    if shards > 1:
+        assert x.size(0) % shards == 0
+        n = x.size(0) // shards
+        preds = []
+        for s in range(shards):      # shared parameter leaves, per-replica buffers (replica 0's are kept)
+            Ps = PG if s == 0 else Params({k: (v if trainable(k) else v.clone()) for k, v in st.g.items()} | {
+                k: gp[k] for k in gp if trainable(k)})
+            preds.append(rigan_forward(Ps, x[s * n:(s + 1) * n], training=True))
+        pred = torch.cat(preds, 0)
+    else:
+        pred = rigan_forward(PG, x, training=True)
     out: Dict[str, object] = {}
     dlosses = []
     g_grads = None
+
+    def g_update_terms(neg):
+        gl, vl, sl, genl = compound_loss(st.vgg, pred, y, neg)
+        gnames = [k for k in gp if trainable(k)]
+        if want_grads:      # d gloss / d pred and its three parts (diagnostics for the tests)
+            for nm, term in (("dpred_vgg", 0.3 * vl), ("dpred_dssim", 0.5 * sl), ("dpred_gen", 0.2 * genl)):
+                out[nm] = torch.autograd.grad(term, pred, retain_graph=True)[0].detach()
+            out["dpred"] = out["dpred_vgg"] + out["dpred_dssim"] + out["dpred_gen"]
+        gg = dict(zip(gnames, torch.autograd.grad(gl, [gp[k] for k in gnames])))
+        out.update(gloss=gl.item(), vgg=vl.item(), dssim=sl.item(), gen=genl.item())
+        return gg
+
     for it in range(2):
         dp = {k: (v.clone().requires_grad_(True) if trainable(k) else v.clone()) for k, v in st.d.items()}
         PD = Params(dp)
-        last = it == 1
+        last = it == 1 and not fresh_d
         d_in = torch.cat([y, pred if last else pred.detach()], 0)
         d_out = discriminator_forward(PD, d_in, training=True)
         pos, neg = torch.chunk(d_out, 2, 0)
@@ -564,14 +602,7 @@ def train_step(st: TrainState, x: Tensor, y: Tensor, want_grads: bool = False) -
         names = [k for k in dp if trainable(k)]
         grads = torch.autograd.grad(dl, [dp[k] for k in names], retain_graph=last, allow_unused=True)
         if last:
-            gl, vl, sl, genl = compound_loss(st.vgg, pred, y, neg)
-            gnames = [k for k in gp if trainable(k)]
-            if want_grads:      # d gloss / d pred and its three parts (diagnostics for the tests)
-                for nm, term in (("dpred_vgg", 0.3 * vl), ("dpred_dssim", 0.5 * sl), ("dpred_gen", 0.2 * genl)):
-                    out[nm] = torch.autograd.grad(term, pred, retain_graph=True)[0].detach()
-                out["dpred"] = out["dpred_vgg"] + out["dpred_dssim"] + out["dpred_gen"]
-            g_grads = dict(zip(gnames, torch.autograd.grad(gl, [gp[k] for k in gnames])))
-            out.update(gloss=gl.item(), vgg=vl.item(), dssim=sl.item(), gen=genl.item())
+            g_grads = g_update_terms(neg)
         st.d_step += 1
         with torch.no_grad():
             for k, g in zip(names, grads):
@@ -583,6 +614,14 @@ def train_step(st: TrainState, x: Tensor, y: Tensor, want_grads: bool = False) -
         dlosses.append(dl.item())
         if want_grads:
             out[f"d_grads_{it}"] = {k: (g.detach() if g is not None else None) for k, g in zip(names, grads)}
+    if fresh_d:
+        dp = {k: v.clone() for k, v in st.d.items()}
+        PD = Params(dp)
+        neg = discriminator_forward(PD, pred, training=True)
+        g_grads = g_update_terms(neg)
+        for k in dp:
+            if not trainable(k):
+                st.d[k] = dp[k].detach()
     st.g_step += 1
     with torch.no_grad():
         for k, g in g_grads.items():

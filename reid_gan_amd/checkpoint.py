@@ -103,7 +103,14 @@ def checkpoint_dict(gs: State, ds: State, epoch: int, total_iters: int, lr: floa
 
 def save_checkpoint(path: str, ts, epoch: int, total_iters: int, lr: Optional[float] = None):
     """ts: a TrainStep.  Writes a file the reference's train.py (--load_chkpt) and test.py load."""
-    torch.save(checkpoint_dict(ts.gs, ts.ds, epoch, total_iters, ts.lr if lr is None else lr), path)
+    ck = checkpoint_dict(ts.gs, ts.ds, epoch, total_iters, ts.lr if lr is None else lr)
+    # A look-ahead plan has already run the next step's spectral-norm power iteration when a step returns: the
+    # weight_u / weight_v saved here are one iteration ahead of what the reference's loop would hold at this point.
+    # The extra key (ignored by the reference's loaders, which read their seven keys by name) lets restore() resume
+    # a look-ahead plan without repeating that iteration.
+    if getattr(ts, "lookahead", False) and getattr(ts, "_d_ready", False):
+        ck["ried_d_prepared"] = True
+    torch.save(ck, path)
 
 
 def load_checkpoint(path: str) -> dict:
@@ -128,6 +135,6 @@ def restore(ts, ck: dict, optimizers: bool = True) -> dict:
         groups = ck["optG_state_dict"].get("param_groups") or []
         if groups and "lr" in groups[0]:
             ts.lr = float(groups[0]["lr"])
-    if hasattr(ts, "weights_changed"):
-        ts.weights_changed()          # a look-ahead plan has prepared its next step with the old weights
+    if hasattr(ts, "weights_changed"):      # a look-ahead plan has prepared its next step with the old weights
+        ts.weights_changed(d_prepared=bool(ck.get("ried_d_prepared", False)))
     return {k: ck.get(k) for k in ("epoch", "total_iters", "lr")}

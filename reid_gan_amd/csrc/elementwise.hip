@@ -944,6 +944,40 @@ extern "C" int ried_bn_backward(const void* dy, long long lddy, const void* x, l
   RIED_CHECK_LAUNCH("ried_bn_backward");
   return RIED_OK;
 }
+// The folded form of ried_bn_backward as its two launches, for callers that must touch the sums between them
+// (synchronised BatchNorm: the per-channel sums are averaged over the data-parallel ranks before they are applied).
+// reduce: folded (ZEROED fp32 [ried_bn_backward_folded_floats(C)]) += the partial sums of g and g * x-hat.
+extern "C" int ried_bn_backward_reduce(const void* dy, long long lddy, const void* x, long long ldx, long long npix,
+                                       int C, const float* save, const float* gamma, const float* beta, int relu,
+                                       float* folded, hipStream_t stream) {
+  CHECK_VIEW("ried_bn_backward_reduce", dy, lddy, C);
+  CHECK_VIEW("ried_bn_backward_reduce", x, ldx, C);
+  RIED_CHECK_ARG(save && gamma && beta && folded && npix > 0 && C <= 8 * EW_THREADS,
+                 "ried_bn_backward_reduce: bad arguments");
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(chan_grid(npix, C, 4, BN_BWD_MAX_ROWS)), dim3(EW_THREADS), 0, stream,
+                     (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, npix, C, save, gamma, beta, relu, (float*)nullptr,
+                     (unsigned*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, 0, folded);
+  RIED_CHECK_LAUNCH("ried_bn_backward_reduce");
+  return RIED_OK;
+}
+// apply: dx from the rows of `folded` (their sum = the sums over the npix pixels, or the mean over ranks of the
+// ranks' sums: the formula divides by npix either way); dgamma / dbeta (may be null) receive the rows' totals.
+extern "C" int ried_bn_backward_apply(const void* dy, long long lddy, const void* x, long long ldx, void* dx,
+                                      long long lddx, long long npix, int C, const float* save, const float* gamma,
+                                      const float* beta, int relu, const float* folded, float* dgamma, float* dbeta,
+                                      int accumulate, hipStream_t stream) {
+  CHECK_VIEW("ried_bn_backward_apply", dy, lddy, C);
+  CHECK_VIEW("ried_bn_backward_apply", x, ldx, C);
+  CHECK_VIEW("ried_bn_backward_apply", dx, lddx, C);
+  RIED_CHECK_ARG(save && gamma && beta && folded && npix > 0 && C <= 8 * EW_THREADS,
+                 "ried_bn_backward_apply: bad arguments");
+  float* dg = (dgamma && dbeta) ? dgamma : nullptr;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(chan_grid(npix, C, 2, 8192)), dim3(EW_THREADS), 0, stream,
+                     (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, (bf16_t*)dx, lddx, npix, C, save, gamma, beta,
+                     relu, folded, BN_BWD_FOLD_ROWS, dg, dbeta, accumulate);
+  RIED_CHECK_LAUNCH("ried_bn_backward_apply");
+  return RIED_OK;
+}
 extern "C" long long ried_bn_backward_scratch_floats(int C) { return (long long)(BN_BWD_MAX_ROWS + 1) * 2 * C; }
 extern "C" long long ried_bn_backward_folded_floats(int C) { return (long long)BN_BWD_FOLD_ROWS * 2 * C; }
 

@@ -128,6 +128,13 @@ class Ctx:
         self._stats_req: List[Tuple[object, str, int]] = []
         self.chain = False                 # True: no activation gradient has two writers, nothing needs zeroing
         self.per_image = False             # forward-only plans: BatchNorm statistics per image (see Generator)
+        # Synchronised BatchNorm (data parallel): a callable that averages an fp32 tensor over the ranks in place, on
+        # the current stream.  Every train-mode layer then runs conv -> bn_sync(its folded sums) -> normalise, and
+        # backward reduce -> bn_sync(the folded backward sums) -> apply; the launches divide by the LOCAL pixel count,
+        # so rank-averaged sums give exactly the statistics and gradients of the global batch.  (One deviation: the
+        # unbiased factor n / (n - 1) of running_var uses the local n.)  Layers run one by one: no sibling groups,
+        # no level-wise job tables.
+        self.bn_sync = None
         self.dx_group: Optional["InputGradGroup"] = None     # open group of sibling 1x1 layers (see InputGradGroup)
         self.build_lane = 0                # lane (stream + scratch set) the layers being built will run on
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
@@ -270,11 +277,11 @@ class Ctx:
         if self.bfold_elems:     # the BatchNorm backward sums the reductions add into
             self.bfold_arena.zero_()
 
-    def sn_sigmas(self):
-        """One power iteration (training) and sigma = u^T W v for every spectral-norm layer; must precede
-        pack_all(), which divides the packed weights by sigma."""
+    def sn_sigmas(self, power_iter: Optional[bool] = None):
+        """One power iteration (training; power_iter=False: none) and sigma = u^T W v for every spectral-norm layer;
+        must precede pack_all(), which divides the packed weights by sigma."""
         if self.sn.jobs is not None:
-            ops.sn_sigma_jobs(self.sn, power_iter=self.training)
+            ops.sn_sigma_jobs(self.sn, power_iter=self.training if power_iter is None else bool(power_iter))
 
     def sn_finish_wgrads(self):
         """After end_backward(): gradients w.r.t. W/sigma (each layer's dwsn) -> gradients of weight_orig."""
@@ -539,6 +546,8 @@ class ConvBN:
         if self.sliced:        # every fold row exists: a job-table launch runs 64-pixel tiles, more than the layer's own
             self.stat_rows = ops.bn_fold_rows()
         ctx.stats(self, "stats", self.stat_rows * 2 * cout, zeroed=self.sliced)
+        if ctx.bn_sync is not None and ctx.training:
+            assert self.sliced and not bias and not shared, "synchronised BatchNorm needs the folded-sums path"
         self.fold = (torch.empty(ops.bn_finalize_fold_floats(cout), dtype=F32, device=ctx.device)
                      if self.stat_rows > 1024 else None)
         self.draw: Optional[View] = None
@@ -551,6 +560,7 @@ class ConvBN:
                 ctx.need_f32(ops.colsum_scratch_floats(cout))
             # small layers: the backward sums are folded with float atomics too (one dependent launch fewer)
             self.bwd_fold = BN_FOLD and BN_BWD_FOLD and self.raw.npix * cout <= BN_FOLD_MAX_ELEMS
+            assert self.bwd_fold or ctx.bn_sync is None, "synchronised BatchNorm needs the folded backward sums"
             if self.bwd_fold:     # (+ 8 words: the grid barrier's counter of the one-launch form sits behind the rows)
                 self.bfold_rows = ops.bn_backward_folded_floats(cout)     # (ctx.stats sets bfold_n = the whole request)
                 ctx.stats(self, "bfold", self.bfold_rows + 8, zeroed="backward")
@@ -585,6 +595,8 @@ class ConvBN:
                 return
             if self.fused_fwd is None:           # (else the sibling group's one convolution has produced raw and the sums)
                 c.conv(self.raw, stats=self.stats, stats_post=2)
+            if ctx.bn_sync is not None:
+                ctx.bn_sync(self.stats)
             self.forward_bn()
             return
         if ctx.training:
@@ -627,6 +639,13 @@ class ConvBN:
 
     def backward_bn(self):
         ctx, st = self.ctx, self.ctx.st
+        if ctx.bn_sync is not None:
+            gamma, beta, rows = st.p[self.bn + ".weight"], st.p[self.bn + ".bias"], self.bfold[:self.bfold_rows]
+            ops.bn_backward_reduce(self.out.g, self.raw, self.save, gamma, beta, rows, relu=self.act)
+            ctx.bn_sync(rows)
+            ops.bn_backward_apply(self.out.g, self.raw, self.draw, self.save, gamma, beta, rows,
+                                  st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=self.act)
+            return
         ops.bn_backward(self.out.g, self.raw, self.draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
                         ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=self.act,
                         accumulate=self.shared, folded=self.bfold if self.bwd_fold else None,
@@ -853,7 +872,7 @@ BN_BWD_ONE = bool(os.environ.get("RIED_BN_BWD_ONE"))
 
 
 def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
-    if not SIBLING_GROUPS or not (ctx.grads or (ctx.training and ctx.st is not None)):
+    if not SIBLING_GROUPS or ctx.bn_sync is not None or not (ctx.grads or (ctx.training and ctx.st is not None)):
         return None
     ctx.dx_group = InputGradGroup(ctx, xin)
     return ctx.dx_group
@@ -889,6 +908,8 @@ class ConvBNC1:
             ctx.need_f32(ops.bn_backward_scratch_floats(cout))
             ctx.need_f32(ops.conv_c1_wgrad_scratch_floats(cout))
             ctx.need_tmp(N * self.Ho * self.Wo * cout)
+            if ctx.bn_sync is not None:
+                ctx.stats(self, "bfold", ops.bn_backward_folded_floats(cout), zeroed="backward")
         self.x: Optional[torch.Tensor] = None
 
     def forward(self, x: torch.Tensor):
@@ -903,6 +924,8 @@ class ConvBNC1:
             return
         if ctx.training:
             ops.conv_c1_fwd(x, w, self.raw, 2, stats=self.stats)
+            if ctx.bn_sync is not None:
+                ctx.bn_sync(self.stats)
             ops.bn_finalize(self.stats, self.stat_rows, self.cout, self.raw.npix, self.save, st.b[bn + ".running_mean"],
                             st.b[bn + ".running_var"], st.b[bn + ".num_batches_tracked"], fold=self.fold)
         else:
@@ -913,8 +936,14 @@ class ConvBNC1:
     def backward(self):
         ctx, st, bn = self.ctx, self.ctx.st, self.prefix + ".bn"
         draw = ctx.tmp_view(self.N, self.Ho, self.Wo, self.cout)
-        ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[bn + ".weight"], st.p[bn + ".bias"], ctx.f32,
-                        st.g[bn + ".weight"], st.g[bn + ".bias"], relu=True)
+        if ctx.bn_sync is not None:
+            ops.bn_backward_reduce(self.out.g, self.raw, self.save, st.p[bn + ".weight"], st.p[bn + ".bias"], self.bfold)
+            ctx.bn_sync(self.bfold)
+            ops.bn_backward_apply(self.out.g, self.raw, draw, self.save, st.p[bn + ".weight"], st.p[bn + ".bias"],
+                                  self.bfold, st.g[bn + ".weight"], st.g[bn + ".bias"])
+        else:
+            ops.bn_backward(self.out.g, self.raw, draw, self.save, st.p[bn + ".weight"], st.p[bn + ".bias"], ctx.f32,
+                            st.g[bn + ".weight"], st.g[bn + ".bias"], relu=True)
         ops.conv_c1_wgrad(self.x, draw, 2, st.g[self.prefix + ".conv.weight"], ctx.f32)   # grads were zeroed
 
 
@@ -1006,7 +1035,8 @@ class Par:
         assert 1 <= len(branches) <= N_LANES
         self.ctx, self.branches = ctx, branches
         self.levels = None
-        if LEVEL_JOBS and ctx.grads and ctx.training and ctx.st is not None and not ctx.per_image:
+        if LEVEL_JOBS and ctx.grads and ctx.training and ctx.st is not None and not ctx.per_image \
+                and ctx.bn_sync is None:
             ctx._late.append(self._build_levels)
 
     # Level-wise execution (small train-mode layers).  The k-th layers of the branches do not depend on each other,
@@ -1363,11 +1393,15 @@ class Generator:
     # first top-level module of each gradient bucket, in forward (= flat parameter) order; the backward pass
     # completes the buckets last to first
     BUCKET_STARTS = ("conv1", "layer_block_3")
+    # top-level modules in forward order (src/rinet.py:55-70); out_conv's gradient is the first one backward computes
+    TOP_LEVEL = ("conv1", "conv2", "layer_block_1", "reduce_grid_1", "layer_block_2", "reduce_grid_2", "layer_block_3",
+                 "expand_grid_1", "layer_block_4", "expand_grid_2", "layer_block_5", "deconv1", "deconv2", "out_conv")
     # (Measured without data parallelism: launching each bucket's deferred weight gradients on a side stream, beside
     # the remaining layers' small kernels, makes the step 0.09 ms slower; they stay at the end of the pass.)
 
     def __init__(self, state: State, N: int, H: int, W: int, grads=True, training=True, device="cuda",
-                 out: Optional[torch.Tensor] = None, per_image_stats: bool = False, grad_buckets: bool = False):
+                 out: Optional[torch.Tensor] = None, per_image_stats: bool = False, grad_buckets: bool = False,
+                 bn_sync=None):
         """out: where the (N,1,H,W) fp32 result goes (default: an own buffer).
         grad_buckets: finish the parameter gradients in two buckets - bottleneck + decoder (81 % of the parameters,
         complete after the first half of the backward pass), then the encoder - instead of all at the end of
@@ -1380,6 +1414,10 @@ class Generator:
         assert H % 16 == 0 and W % 16 == 0, "RIGAN needs H, W divisible by 16 (skip connections must line up)"
         self.st = state
         self.ctx = ctx = Ctx(state, device, grads, training)
+        if bn_sync is not None:      # (see Ctx.bn_sync)
+            if not (grads and training and BN_FOLD):
+                raise ValueError("synchronised BatchNorm: training plans with folded statistics only")
+            ctx.bn_sync = bn_sync
         # every weight gradient of this network runs in the grouped launches: the grid is shared by all layers, so a
         # layer needs far fewer blocks of its own (fewer split-K slabs to write and reduce) than a launch per layer
         ctx.splitk_target = int(os.environ.get("RIED_SPLITK_TARGET_G", "0"))
@@ -1396,6 +1434,25 @@ class Generator:
         body = Seq()
         self.bucket_first = [0]        # index into body.layers of the first layer of buckets 1, 2, ... (bucket 0: conv1)
         bucketed = grads and grad_buckets
+        # [lo, hi) of the flat parameter / gradient buffer per bucket.  The flat layout follows the key order of the
+        # state dict the caller passed: with the reference's order (module definition order) each bucket's parameters
+        # are one contiguous range; with any other order (sorted keys, say) they may interleave, and then the plan
+        # keeps a single bucket rather than exchange a range that holds unfinished gradients.
+        self.bucket_ranges = [(0, state.flat.numel())]
+        if bucketed:
+            first_late = self.TOP_LEVEL.index(self.BUCKET_STARTS[1])
+            late = set(self.TOP_LEVEL[first_late:])
+            spans = [[None, 0], [None, 0]]
+            for k, off in state.offs.items():
+                b = 1 if k.split(".")[0] in late else 0
+                end = off + (state.p[k].numel() + 3) // 4 * 4
+                spans[b][0] = off if spans[b][0] is None else min(spans[b][0], off)
+                spans[b][1] = max(spans[b][1], end)
+            (lo0, hi0), (lo1, hi1) = spans
+            if lo0 == 0 and lo1 is not None and hi0 <= lo1 and hi1 == state.flat.numel():
+                self.bucket_ranges = [(0, lo1), (lo1, hi1)]
+            else:
+                bucketed = False
         starts_at = self.BUCKET_STARTS if bucketed else ()
 
         def bucket(name):
@@ -1428,11 +1485,6 @@ class Generator:
         assert self.out.shape == (N, 1, H, W) and self.out.dtype == F32 and self.out.is_contiguous()
         ctx.finalize()
         self.x = None
-        # [lo, hi) of the flat parameter / gradient buffer per bucket (parameters are laid out in module order)
-        starts = [state.offs[min((k for k in state.offs if k.startswith(p + ".")), key=state.offs.get)]
-                  for p in (starts_at or self.BUCKET_STARTS[:1])]
-        assert starts == sorted(starts) and starts[0] == 0
-        self.bucket_ranges = list(zip(starts, starts[1:] + [state.flat.numel()]))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         assert x.shape == (self.N, 1, self.H, self.W) and x.dtype == F32 and x.is_contiguous()
@@ -1718,10 +1770,12 @@ class Discriminator:
         """True if forward_images() accepts a sub-range of the batch."""
         return all(l.fused for l in self.layers if isinstance(l, Attn))
 
-    def prepare(self):
+    def prepare(self, power_iter: Optional[bool] = None):
         """The part of a forward pass that depends on the weights only: one power iteration per spectral-norm layer
-        (src/rinet.py:138 runs it in every training-mode forward), sigma, and the packed W / sigma."""
-        self.ctx.sn_sigmas()
+        (src/rinet.py:138 runs it in every training-mode forward), sigma, and the packed W / sigma.
+        power_iter=False: sigma and the packed weights from the vectors as they are (they already hold this
+        forward's iteration: a resumed look-ahead plan)."""
+        self.ctx.sn_sigmas(power_iter)
         self.ctx.begin_forward()
 
     def forward_images(self, x_img: torch.Tensor, n0: int, n1: int) -> Slot:

@@ -30,6 +30,12 @@ def require_gpu():
     lib.load()
 
 
+def install_crash_backtrace(log_path: Optional[str] = None, stderr_fd: int = -1):
+    """On a fatal signal, write the native frames of the faulting thread to stderr (or stderr_fd) and to log_path,
+    then pass the signal on to the handler installed before (faulthandler).  Needs no GPU."""
+    lib.ried_install_crash_backtrace(log_path.encode() if log_path else None, int(stderr_fd))
+
+
 @dataclass
 class View:
     """Channels [0, C) of an NHWC bf16 tensor: pixel p's channels start at ptr + 2*p*ld."""
@@ -416,6 +422,19 @@ def bn_backward(dy: View, x: View, dx: View, save, gamma, beta, scratch, dgamma=
     lib.ried_bn_backward(dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta),
                          int(relu), _p(scratch), _p(dgamma), _p(dbeta), int(accumulate), _p(counter), _p(folded),
                          _stream())
+
+
+def bn_backward_reduce(dy: View, x: View, save, gamma, beta, folded: torch.Tensor, relu=True):
+    """First launch of the folded BatchNorm backward: folded (zeroed) += sums of g and g * x-hat."""
+    lib.ried_bn_backward_reduce(dy.ptr, dy.ld, x.ptr, x.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta), int(relu),
+                                _p(folded), _stream())
+
+
+def bn_backward_apply(dy: View, x: View, dx: View, save, gamma, beta, folded: torch.Tensor, dgamma=None, dbeta=None,
+                      relu=True, accumulate=False):
+    """Second launch: dx (and the parameter gradients) from the rows of `folded`."""
+    lib.ried_bn_backward_apply(dy.ptr, dy.ld, x.ptr, x.ld, dx.ptr, dx.ld, x.npix, x.C, _p(save), _p(gamma), _p(beta),
+                               int(relu), _p(folded), _p(dgamma), _p(dbeta), int(accumulate), _stream())
 
 
 def bn_backward_folded_floats(C: int) -> int:

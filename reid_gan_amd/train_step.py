@@ -46,25 +46,75 @@ F32 = torch.float32
 SC_MEAN_POS, SC_MEAN_NEG, SC_DLOSS, SC_CPOS, SC_CNEG, SC_VGG, SC_SSIM, SC_DSSIM, SC_GEN, SC_GLOSS = range(10)
 SC_DLOSS1, SC_DLOSS2 = 10, 11
 
-# Captured graphs are destroyed with the object that owns them.  An earlier state of this package crashed in the
-# runtime (host segmentation fault in hipGraphLaunch) at the first replay of a capture made after a many-stream graph
-# had been destroyed, and therefore kept every graph until the process ended.  The sequence no longer reproduces:
-# tools/graph_destroy_repro.py (capture A, capture B, destroy A, replay B, capture C, replay C; torch-only graphs
-# with and without a shared pool, and the real step) and the whole GPU test suite run clean with graphs freed.
-# RIED_RETAIN_GRAPHS=1 brings the old behaviour back (a leak of a few host objects per capture).
+# Lifetime of captured graphs.  Destroying a many-stream captured graph has crashed this runtime twice: a host
+# segmentation fault in hipGraphLaunch at the first replay of a capture made after such a graph had been destroyed,
+# and - with graphs freed whenever Python's garbage collector dropped their owner - a host abort in the middle of
+# unrelated CPU work some tests after several such owners had gone out of scope.  Neither sequence reproduces in a
+# small script.  So, by default, a graph that has been captured is never destroyed: when its owner is closed
+# (close(), or garbage collection) the graph object is parked in _RETAINED_GRAPHS until the process ends.  A parked
+# graph costs its host-side node list and a private, near-empty memory pool (no step allocates during capture).
+# RIED_FREE_GRAPHS=1 destroys graphs in close() instead - synchronise, drop in reverse capture order (segments
+# chain their memory pools, the last captured must die first), synchronise - and never from the garbage collector.
 _RETAINED_GRAPHS = []
 
 
+def _free_graphs() -> bool:
+    return bool(os.environ.get("RIED_FREE_GRAPHS"))
+
+
 def _retain(graph):
-    if os.environ.get("RIED_RETAIN_GRAPHS"):
+    """Called on every graph at creation: parks it unless RIED_FREE_GRAPHS is set."""
+    if not _free_graphs():
         _RETAINED_GRAPHS.append(graph)
     return graph
+
+
+def _park_on_del(owner):
+    try:
+        gs = getattr(owner, "graphs", None)
+        gs = [g for g, _ in gs] if gs else []
+        if getattr(owner, "graph", None) is not None:
+            gs.append(owner.graph)
+        for g in gs:
+            if not any(g is r for r in _RETAINED_GRAPHS):
+                _RETAINED_GRAPHS.append(g)
+    except Exception:           # interpreter shutdown: globals may be gone, and then nothing needs keeping
+        pass
+
+
+def _dispose(graphs):
+    """Let go of captured graphs (a list, oldest first).  Parked graphs stay alive; with RIED_FREE_GRAPHS=1 they are
+    destroyed here, explicitly and in order, with the device idle on both sides."""
+    graphs = [g for g in graphs if g is not None]
+    if not graphs:
+        return
+    if not _free_graphs():
+        for g in graphs:
+            if not any(g is r for r in _RETAINED_GRAPHS):
+                _RETAINED_GRAPHS.append(g)
+        return
+    torch.cuda.synchronize()
+    while graphs:
+        g = graphs.pop()          # last captured first
+        g.reset()
+        del g
+    torch.cuda.synchronize()
 
 
 class TrainStep:
     def __init__(self, g_sd: Dict[str, torch.Tensor], d_sd: Dict[str, torch.Tensor], vgg: Dict[str, torch.Tensor],
                  batch: int, H: int, W: int, lr: float = 1e-4, weights=(0.3, 0.5, 0.2), device="cuda",
-                 use_graph: bool = True, process_group=None, lookahead: bool = False):
+                 use_graph: bool = True, process_group=None, lookahead: bool = False, fresh_d: bool = False,
+                 sync_bn: bool = False):
+        """fresh_d: the generator's adversarial term is taken from a NEW discriminator forward on the prediction after
+        both discriminator updates - the `D_gen = Dnet(pred)` the reference's author left commented out at
+        src/train.py:171 - instead of from the second iteration's forward (whose weights are one Adam step older).
+        It costs one more discriminator forward on the prediction half and changes the reported gloss, so it is off
+        by default.  sync_bn (with a process group): the generator's train-mode BatchNorm layers use the statistics of
+        the GLOBAL batch (their per-channel sums are averaged over the ranks, forward and backward), so the step
+        equals the single-process step at the global batch; per-replica statistics - what the nn.DataParallel left
+        commented out at src/train.py:95-96 would compute - are the default.  One small all-reduce per BatchNorm
+        layer and direction: the step then runs eagerly (no graph), for parity checks rather than throughput."""
         ops.require_gpu()
         self.B, self.H, self.W, self._lr = batch, H, W, float(lr)
         self.wv, self.ws, self.wg = weights
@@ -86,8 +136,13 @@ class TrainStep:
         # The discriminator reads cat([target, prediction]) (train.py:158): the target batch and the generator's
         # output ARE the two halves of that buffer, so nothing is copied to build it.
         self.d_in = torch.zeros(2 * B, 1, H, W, dtype=F32, device=device)
+        self.fresh_d = bool(fresh_d)
+        self.sync_bn = bool(sync_bn) and process_group is not None
+        if self.sync_bn:
+            use_graph = False
         self.G = Generator(self.gs, B, H, W, grads=True, training=True, device=device,
-                           grad_buckets=process_group is not None, out=self.d_in[B:])
+                           grad_buckets=process_group is not None, out=self.d_in[B:],
+                           bn_sync=self.xch.sync if self.sync_bn else None)
         self.D = Discriminator(self.ds, 2 * B, H, W, grads=True, training=True, device=device)
         self.V = Vgg(vgg, B, H, W, grads=True, device=device)
         self.x = torch.zeros(B, 1, H, W, dtype=F32, device=device)
@@ -108,7 +163,8 @@ class TrainStep:
         self._d_prepared = False
         # look-ahead: see the module docstring.  With a process group the discriminator's Adam step waits for an
         # all-reduce that is only awaited after the generator backward, so there is nothing to run the work beside.
-        self.lookahead = bool(lookahead) and process_group is None and not os.environ.get("RIED_NO_LOOKAHEAD")
+        self.lookahead = (bool(lookahead) and process_group is None and not self.fresh_d
+                          and not os.environ.get("RIED_NO_LOOKAHEAD"))
         self.pre_dreal = self.lookahead and self.D.splittable and not os.environ.get("RIED_NO_PRE_DREAL")
         # which of the target-only pieces run at the end of the previous step (the others: beside the generator forward)
         self.la_vgg = self.lookahead and not os.environ.get("RIED_LA_VGG_FRONT")
@@ -117,6 +173,7 @@ class TrainStep:
         self._primed = False        # the targets in self.y have been prepared (by the previous step, or by _prime())
         self._d_ready = False       # the discriminator's weights are prepared for the next step's first iteration
         self._next_key = None       # identifies the tensor announced as y_next
+        self._next_ref = None       # ... and keeps it alive, so that no other tensor can take its address meanwhile
         self._ynext_is_y = False    # the y_next buffer holds a copy of self.y (nothing was announced)
         self._warmed = False        # every kernel of the step has been loaded (an eager step has run)
         self.graphs = None          # [(graph, tensor to all-reduce after it or None)]
@@ -136,7 +193,26 @@ class TrainStep:
         value = float(value)
         if value != self._lr:
             self._lr = value
-            self.graphs = None
+            self._drop_graphs()
+
+    def _drop_graphs(self):
+        if self.graphs is not None:
+            graphs, self.graphs = [g for g, _ in self.graphs], None
+            _dispose(graphs)
+
+    def close(self):
+        """Release the captured graphs (see _dispose); the plan can still step afterwards (it captures again).
+        Call it when done with the object instead of leaving that to the garbage collector."""
+        self._drop_graphs()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):          # never destroy a graph from the garbage collector: park what close() did not see
+        _park_on_del(self)
 
     @property
     def exchange(self):
@@ -182,13 +258,17 @@ class TrainStep:
         if s != torch.cuda.current_stream():
             torch.cuda.current_stream().wait_stream(s)
 
-    def _d_iteration(self, last: bool):
+    def _d_iteration(self, last: bool, first: Optional[bool] = None):
+        """One discriminator iteration (train.py:156-165).  first: it is the step's first one (what was prepared
+        beside the generator forward belongs to it); last: the generator loss and backward hang on this iteration's
+        forward (False for both iterations of a fresh_d step)."""
         B, sc, D = self.B, self.sc, self.D
-        if not last and self.pre_dreal:
+        first = (not last) if first is None else first
+        if first and self.pre_dreal:
             out = D.forward_images(self.d_in, B, 2 * B)      # the target half ran at the end of the previous step
-        elif not last and self._d_side is None and self._d_prepared:
+        elif first and self._d_side is None and self._d_prepared:
             out = D.forward_images(self.d_in, 0, 2 * B)      # spectral norms and repacks ran beside the generator forward
-        elif last or self._d_side is None:
+        elif not first or self._d_side is None:
             out = D.forward(self.d_in)
         else:          # the target half has been running beside the generator forward (see _body)
             out = D.forward_images(self.d_in, B, 2 * B)
@@ -199,7 +279,7 @@ class TrainStep:
         ops.dot(out.v.images(0, B), None, 1.0 / n, sc[SC_MEAN_POS:])
         ops.dot(out.v.images(B, 2 * B), None, 1.0 / n, sc[SC_MEAN_NEG:])
         yield [("sync", sc[SC_MEAN_POS:SC_MEAN_NEG + 1])]    # the hinge acts on the GLOBAL batch means
-        ops.dloss_scalars(sc, n, keep=sc[SC_DLOSS2 if last else SC_DLOSS1:])
+        ops.dloss_scalars(sc, n, keep=sc[SC_DLOSS1 if first else SC_DLOSS2:])
         if last:       # the generator's gradient goes through D as it is now; D's own backward reuses the buffers after
             self._g_loss_backward(n)
         # D's own backward (large kernels) on a side stream beside the generator backward (small, latency-bound
@@ -221,21 +301,44 @@ class TrainStep:
             yield [("sync", self.ds.flat_grad)]
             self.ds.adam(4.0 * self.lr)
             return
-        self.gs.zero_grad()
-        gr, first = self.G.bucket_ranges, True
-        for b in self.G.backward_buckets(self.dpred):
-            ev = [("issue", ("g", b), self.gs.flat_grad[gr[b][0]:gr[b][1]])]
-            if first:
-                self._join(side)
-                ev.insert(0, ("issue", "d", self.ds.flat_grad))
-                first = False
-            if b == 0:      # the last bucket: everything is needed next
-                ev += [("wait", "d")] + [("wait", ("g", k)) for k in reversed(range(len(gr)))]
-            yield ev
+        yield from self._g_backward(side)
         if self.lookahead:
             self._join(side)
         else:
             self.ds.adam(4.0 * self.lr)
+
+    def _g_backward(self, side=None):
+        """The generator backward from self.dpred, bucket by bucket.  side: the stream the last discriminator backward
+        runs on (its flat gradient is exchanged together with the generator's first bucket), or None when the
+        discriminator has been updated already."""
+        self.gs.zero_grad()
+        gr, first = self.G.bucket_ranges, True
+        for b in self.G.backward_buckets(self.dpred):
+            ev = [("issue", ("g", b), self.gs.flat_grad[gr[b][0]:gr[b][1]])]
+            if first and side is not None:
+                self._join(side)
+                ev.insert(0, ("issue", "d", self.ds.flat_grad))
+            first = False
+            if b == 0:      # the last bucket: everything is needed next
+                ev += ([("wait", "d")] if side is not None else []) + [("wait", ("g", k)) for k in reversed(range(len(gr)))]
+            yield ev
+
+    def _fresh_d_g_loss(self):
+        """fresh_d: D(pred) with the discriminator as it is after both updates (a training-mode forward: one more
+        power iteration of every spectral norm, as the module's forward hook would run), then the generator loss and
+        backward through it."""
+        B, sc, D = self.B, self.sc, self.D
+        if D.splittable:
+            D.prepare()
+            out = D.forward_images(self.d_in, B, 2 * B)
+        else:
+            out = D.forward(self.d_in)
+        n = out.v.npix // 2 * out.v.C
+        sc[SC_MEAN_NEG:SC_MEAN_NEG + 1].zero_()
+        ops.dot(out.v.images(B, 2 * B), None, 1.0 / n, sc[SC_MEAN_NEG:])
+        yield [("sync", sc[SC_MEAN_NEG:SC_MEAN_NEG + 1])]
+        self._g_loss_backward(n)
+        yield from self._g_backward(None)
 
     def _prep_targets(self, weights: bool = True):
         """What the step needs from the target batch in self.y and the weights as they are before it starts.
@@ -321,19 +424,27 @@ class TrainStep:
             self._vgg_side = None
         assert pred.data_ptr() == self.d_in[B:].data_ptr()
         yield from self._d_iteration(last=False)
-        yield from self._d_iteration(last=True)
+        if self.fresh_d:
+            yield from self._d_iteration(last=False, first=False)
+            yield from self._fresh_d_g_loss()
+        else:
+            yield from self._d_iteration(last=True)
         self.gs.adam(self.lr)
 
     def _run_eager(self):
         for ev in self._body():
             self._handle(ev)
 
-    def weights_changed(self):
+    def weights_changed(self, d_prepared: bool = False):
         """Tell the plan that the networks' weights were written from outside (a checkpoint restore): what a
-        look-ahead plan prepared for its next step with the old weights is discarded and done again.  (A checkpoint
-        saved after a look-ahead step holds spectral-norm vectors that are one power iteration ahead of the plain
-        plan's at the same point: that iteration belongs to the next step and has been run already.)"""
+        look-ahead plan prepared for its next step with the old weights is discarded and done again.
+        d_prepared: the restored spectral-norm vectors already include the next step's power iteration (a checkpoint
+        written after a look-ahead step: that iteration belongs to the next step and had been run when the file was
+        saved).  A look-ahead plan then rebuilds sigma and the packed weights from those vectors WITHOUT iterating
+        again, so the resumed run continues exactly as the uninterrupted one; a plain plan cannot take the iteration
+        back and runs one more than the uninterrupted plain run would have."""
         self._primed = self._d_ready = False
+        self._resume_prepared = bool(d_prepared) and self.lookahead
 
     @staticmethod
     def _key(t: torch.Tensor):
@@ -341,6 +452,9 @@ class TrainStep:
 
     def _prime(self):
         """Look-ahead: prepare the targets in self.y now (first step, or a y that was not announced)."""
+        if getattr(self, "_resume_prepared", False):      # vectors restored one iteration ahead: sigma + repack only
+            self.D.prepare(power_iter=False)
+            self._d_ready, self._resume_prepared = True, False
         self._prep_targets(weights=not self._d_ready)
         self._primed = self._d_ready = True
 
@@ -353,17 +467,19 @@ class TrainStep:
         look-ahead plan then repeats the batch unless y_next announces another)."""
         if x is not None:
             self.x.copy_(x, non_blocking=True)
-            announced = self.lookahead and self._primed and self._next_key is not None and self._key(y) == self._next_key
+            # (the announced tensor is kept alive in _next_ref, so its address cannot have gone to another batch)
+            announced = (self.lookahead and self._primed and self._next_ref is not None
+                         and self._key(y) == self._next_key)
             if not announced:            # (else self.y holds these targets already, prepared)
                 self.y.copy_(y, non_blocking=True)
                 self._primed = False
         if self.lookahead:
             if y_next is not None:
                 self.y_next.copy_(y_next, non_blocking=True)
-                self._next_key, self._ynext_is_y = self._key(y_next), False
+                self._next_key, self._next_ref, self._ynext_is_y = self._key(y_next), y_next, False
             elif x is not None or not self._ynext_is_y:      # nothing announced: the end of the step re-prepares this batch
                 self.y_next.copy_(self.y)
-                self._next_key, self._ynext_is_y = None, True
+                self._next_key, self._next_ref, self._ynext_is_y = None, None, True
             if self.use_graph and self.graphs is None:
                 self._capture()
             if not self._primed:
@@ -432,7 +548,12 @@ class TrainStep:
             self.y.copy_(s["y"])
 
     def losses(self) -> Dict[str, float]:
-        """Host read of the last step's scalars (synchronises)."""
+        """Host read of the last step's scalars (synchronises).  Raises if a one-launch BatchNorm backward
+        (RIED_BN_BWD_ONE=1) ever gave up at its grid barrier: the gradients of that launch are wrong."""
+        from . import engine
+        if engine.BN_BWD_ONE and ops.barrier_timeouts():
+            raise RuntimeError(f"{ops.barrier_timeouts()} blocks timed out at a grid barrier (RIED_BN_BWD_ONE): the "
+                               "launch was not resident at once; BatchNorm gradients of this run are invalid")
         s = self.sc.clone()
         if self.xch is not None:
             self.xch.sync(s)
@@ -488,6 +609,21 @@ class InferenceEngine:
                     self._body()
             self.graph.replay()
         return self.G.out, self.sums
+
+    def close(self):
+        """Release the captured graph (see _dispose); a later run() captures again."""
+        if self.graph is not None:
+            g, self.graph = self.graph, None
+            _dispose([g])
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):          # never destroy a graph from the garbage collector: park what close() did not see
+        _park_on_del(self)
 
     def measures(self, sums: torch.Tensor):
         """Per-slice ((psnr, ssim, rmse) original, (psnr, ssim, rmse) prediction) as Python floats."""

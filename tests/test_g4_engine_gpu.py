@@ -35,49 +35,7 @@ from oracle import ried_oracle as O
 from reid_gan_amd import engine, ops
 from reid_gan_amd.synth import synth_state, synth_batch, synth_vgg
 from reid_gan_amd.train_step import TrainStep, InferenceEngine
-
-DEV = "cuda"
-G_SEED, D_SEED = 101, 202
-
-
-def nchw(v):
-    return v.torch().float().cpu().permute(0, 3, 1, 2).contiguous()
-
-
-class emu:
-    """with emu(): the oracle rounds to bf16 wherever the HIP path stores bf16."""
-
-    def __enter__(self):
-        O.set_bf16_emulation(True)
-
-    def __exit__(self, *a):
-        O.set_bf16_emulation(False)
-
-
-def act_close(got, ref, what, mx=1e-1, mean=3e-2):
-    got, ref = got.double(), ref.double()
-    e = (got - ref).abs()
-    assert e.max().item() <= mx * ref.abs().max().item(), f"{what}: max err {e.max().item():.4g} vs {ref.abs().max().item():.4g}"
-    assert e.mean().item() <= mean * ref.abs().mean().item() + 1e-12, f"{what}: mean err {e.mean().item():.4g} vs {ref.abs().mean().item():.4g}"
-
-
-def grad_close(got, ref, what, cos=0.99, ratio=0.05):
-    got, ref = got.double().flatten(), ref.double().flatten()
-    ng, nr = got.norm().item(), ref.norm().item()
-    if nr < 1e-12:
-        assert ng < 1e-6, what
-        return
-    c = torch.dot(got, ref).item() / (ng * nr + 1e-30)
-    assert c >= cos, f"{what}: cosine {c:.5f}"
-    assert abs(ng / nr - 1) <= ratio, f"{what}: norm ratio {ng / nr:.4f}"
-
-
-def g_state():
-    return synth_state([(n, s) for n, s, _ in O.rigan_spec()], G_SEED)
-
-
-def d_state():
-    return synth_state([(n, s) for n, s, _ in O.discriminator_spec()], D_SEED)
+from gpu_util import DEV, nchw, emu, act_close, grad_close, g_state, d_state, weights_agree
 
 
 def test_generator_forward_backward_vs_oracle_and_golden(golden_dir):
@@ -431,18 +389,6 @@ def test_inference_at_the_benchmark_size_vs_oracle():
         for a, b in zip(got[i][1], res[i][1]):
             assert abs(a - b) <= 2e-2 * abs(b), (i, got[i][1], res[i][1])
 
-
-def weights_agree(a, b, steps=2):
-    """Two runs of the same `steps` steps.  The few float atomics left in the step (loss sums) differ in the last bit
-    between runs, and Adam's first updates are lr * sign(gradient)-like: a weight whose gradient is almost zero can
-    move the other way (up to 2 * lr per step apart: lr 1e-4 for G, 4e-4 for D).  So: nearly all weights agree
-    tightly, and none is further apart than those sign flips allow."""
-    for st_a, st_b, lr in ((a.gs, b.gs, 1e-4), (a.ds, b.ds, 4e-4)):
-        d = (st_a.flat - st_b.flat).abs()
-        assert (d > 1.5 * steps * lr).float().mean().item() <= 1e-4, (lr, d.max().item())
-        assert d.max().item() <= 2 * steps * lr * 1.05, (lr, d.max().item())
-
-
 def test_segmented_graphs_equal_single_graph(monkeypatch):
     """With several ranks the step is captured as graph segments split at the collectives (and the side streams
     must rejoin before each split).  Here the collectives are stubbed out (identical replicas: the mean over ranks
@@ -465,32 +411,38 @@ def test_segmented_graphs_equal_single_graph(monkeypatch):
     weights_agree(one, seg)
 
 
-def test_train_step_through_a_one_rank_rccl_group(monkeypatch):
-    """The data-parallel form of the step on one GPU: a process group of one rank (backend nccl = RCCL), so the
-    graph segments are replayed with real all-reduces issued between them on the same stream.  The mean over one
-    rank is the identity: losses and weights must equal the single-graph step."""
-    import socket
-    import torch.distributed as dist
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    B, H = 4, 64
-    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
-    x, y = synth_batch(B, H, seed=98)
-    monkeypatch.setattr(engine, "BN_FOLD", False)
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-    try:
-        one = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
-        par = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True, process_group=dist.group.WORLD)
-        for ts in (one, par):
-            ts.step(x.to(DEV), y.to(DEV))
-            ts.step()
+def test_gradient_buckets_follow_the_state_dict_order(monkeypatch):
+    """The data-parallel plan exchanges the generator's gradient in two ranges of the flat buffer.  The flat layout
+    follows the key order of the state dict: in the reference's order the bottleneck + decoder parameters are one
+    contiguous tail; with sorted keys they interleave with the encoder's, and the plan must fall back to one bucket
+    (exchanging a range that still holds unfinished gradients would corrupt them silently)."""
+    monkeypatch.setattr(engine, "BN_FOLD", False)        # fixed-order reductions: the two plans must agree closely
+    sd = g_state()
+    st = engine.State(sd, DEV)
+    G = engine.Generator(st, 2, 64, 64, grad_buckets=True)
+    assert len(G.bucket_ranges) == 2 and G.bucket_ranges[0][0] == 0 and G.bucket_ranges[1][1] == st.flat.numel()
+    lo1 = G.bucket_ranges[1][0]
+    late = set(G.TOP_LEVEL[G.TOP_LEVEL.index("layer_block_3"):])
+    for k, off in st.offs.items():
+        assert (off >= lo1) == (k.split(".")[0] in late), k
+    shuffled = {k: sd[k] for k in sorted(sd)}
+    st2 = engine.State(shuffled, DEV)
+    G2 = engine.Generator(st2, 2, 64, 64, grad_buckets=True)
+    assert G2.bucket_ranges == [(0, st2.flat.numel())] and G2.ctx.n_buckets == 1
+    # ... and the single-bucket plan computes the same gradients
+    x, _ = synth_batch(2, 64, seed=7)
+    dout = (torch.randn(2, 1, 64, 64, generator=torch.Generator().manual_seed(5)) * 1e-3).to(DEV)
+    grads = []
+    for s, g in ((st, G), (st2, G2)):
+        g.forward(x.to(DEV))
+        s.zero_grad()
+        ys = list(g.backward_buckets(dout))
         torch.cuda.synchronize()
-        assert par.world == 1 and len(par.graphs) > 3 and len(one.graphs) == 1
-        a, b = one.losses(), par.losses()
-        for k in a:
-            assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
-        weights_agree(one, par)
-    finally:
-        dist.destroy_process_group()
+        grads.append((ys, {k: s.g[k].float().cpu().clone() for k in s.g}))
+    assert grads[0][0] == [1, 0] and grads[1][0] == [0]
+    a = torch.cat([grads[0][1][k].flatten() for k in sorted(sd) if k in grads[0][1]])
+    b = torch.cat([grads[1][1][k].flatten() for k in sorted(sd) if k in grads[1][1]])
+    grad_close(a, b, "two buckets vs one", cos=0.995, ratio=0.03)
 
 
 def test_slice_inference_is_the_batch_one_loop():
@@ -598,157 +550,3 @@ def test_inference_at_the_benchmark_size_with_and_without_sibling_groups(monkeyp
     for i in range(B):
         for u, v in zip(ma[i][1], mb[i][1]):
             assert abs(u - v) <= 5e-3 * abs(v) + 1e-5, (i, ma[i], mb[i])
-
-
-def test_optional_step_overlaps_give_the_same_step(monkeypatch):
-    """The switchable parts of the captured step - the discriminator's weight preparation beside the generator
-    forward (on by default) and its pass over the target half there too (off by default: measured slower) - change
-    the order of launches, not the arithmetic: same losses and weights as the step without them."""
-    B, H = 4, 64
-    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
-    x, y = synth_batch(B, H, seed=98)
-    monkeypatch.setattr(engine, "BN_FOLD", False)        # fixed-order reductions: the runs must agree closely
-    plain = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
-    plain.overlap_dprep = False
-    dreal = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
-    dreal.overlap_dreal = True
-    default = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
-    assert default.overlap_dprep and not default.overlap_dreal
-    for ts in (plain, dreal, default):
-        ts.step(x.to(DEV), y.to(DEV))
-        ts.step()
-    torch.cuda.synchronize()
-    a = plain.losses()
-    for other in (dreal, default):
-        b = other.losses()
-        for k in a:
-            assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
-        weights_agree(plain, other)
-
-
-@pytest.mark.parametrize("use_graph", [True, False])
-def test_lookahead_steps_equal_plain_steps(monkeypatch, use_graph):
-    """lookahead=True: the target-only work of a step (VGG features of y, the first discriminator iteration's
-    weight preparation and its pass over the target half) is done for the NEXT batch at the end of the current
-    step.  The same kernels on the same data in another place: three steps over three different batches give the
-    losses and weights of the plain plan - with every next batch announced, with none announced (each step then
-    prepares its own targets), and with a wrong announcement (detected: the tensor passed is not the announced one)."""
-    B, H = 4, 64
-    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
-    batches = [tuple(t.to(DEV) for t in synth_batch(B, H, seed=60 + i)) for i in range(4)]
-    monkeypatch.setattr(engine, "BN_FOLD", False)        # fixed-order reductions: the runs must agree closely
-    plain = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=use_graph)
-    ahead = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=use_graph, lookahead=True)
-    blind = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=use_graph, lookahead=True)
-    wrong = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=use_graph, lookahead=True)
-    assert ahead.lookahead and ahead.pre_dreal and not plain.lookahead
-    for i in range(3):
-        x, y = batches[i]
-        plain.step(x, y)
-        ahead.step(x, y, y_next=batches[i + 1][1])
-        blind.step(x, y)
-        wrong.step(x, y, y_next=batches[(i + 2) % 4][1])
-        torch.cuda.synchronize()
-        a = plain.losses()
-        for name, other in (("ahead", ahead), ("blind", blind), ("wrong", wrong)):
-            b = other.losses()
-            for k in a:
-                assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (name, i, k, a[k], b[k])
-    for other in (ahead, blind, wrong):
-        weights_agree(plain, other, steps=3)
-    # replays without arguments repeat the batch: same as passing it again
-    x, y = batches[2]
-    plain.step(x, y); plain.step(x, y)
-    blind.step(); blind.step()
-    torch.cuda.synchronize()
-    a, b = plain.losses(), blind.losses()
-    for k in a:
-        assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-6, (k, a[k], b[k])
-
-
-def test_training_plan_with_the_one_launch_batchnorm_backward(monkeypatch):
-    """RIED_BN_BWD_ONE=1: the BatchNorm backward of small layers as one launch with a grid barrier (off by default:
-    measured equal).  The same folded sums in another order: the step agrees with the default plan up to the rounding
-    of those sums, the launch count drops, and no block ever gave up at a barrier."""
-    B, H = 4, 64
-    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
-    x, y = synth_batch(B, H, seed=96)
-    base = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
-    monkeypatch.setattr(engine, "BN_BWD_ONE", True)
-    one = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True)
-    n_one = sum(1 for m in one.G.body.layers for l in _walk(m) if isinstance(l, engine.ConvBN) and l.bwd_one)
-    assert n_one >= 40, n_one
-    assert not any(isinstance(l, engine.ConvBN) and l.bwd_one for m in base.G.body.layers for l in _walk(m))
-    for ts in (base, one):
-        ts.step(x.to(DEV), y.to(DEV))
-    torch.cuda.synchronize()
-    a, b = base.losses(), one.losses()
-    for k in ("dloss1", "dloss2", "gloss", "vgg", "dssim", "gen"):
-        assert abs(a[k] - b[k]) <= 2e-3 * abs(a[k]) + 1e-5, (k, a[k], b[k])
-    gf = torch.cat([one.gs.g[k].float().flatten() for k in sorted(one.gs.g)]).cpu()
-    gb = torch.cat([base.gs.g[k].float().flatten() for k in sorted(base.gs.g)]).cpu()
-    grad_close(gf, gb, "all generator gradients", cos=0.98, ratio=0.05)
-    assert ops.barrier_timeouts() == 0
-
-
-def test_inference_with_the_fused_input_transform(monkeypatch):
-    """Forward-only plans can let the consumer of an inner BasicConv2d layer normalise that layer's raw output inside
-    its own kernel (ried_conv2d_xf; off by default: measured slower).  Same prediction and metrics as the plan that
-    writes every normalised tensor, up to bf16 rounding of tensors that are no longer stored."""
-    sd = g_state()
-    B, H = 4, 256
-    x, y = synth_batch(B, H, seed=79)
-    xd, yd = x.to(DEV), y.to(DEV)
-    a = InferenceEngine(sd, B, H, H)
-    pa, sa = a.run(xd, yd)
-    pa, ma = pa.cpu().clone(), a.measures(sa)
-    monkeypatch.setattr(engine, "XF_FUSE", True)
-    b = InferenceEngine(sd, B, H, H)
-    fused = [l for m in b.G.body.layers for l in _walk(m) if isinstance(l, engine.ConvBN) and l.core.xf_src is not None]
-    assert len(fused) >= 10, len(fused)
-    pb, sb = b.run(xd, yd)
-    pb, mb = pb.cpu(), b.measures(sb)
-    act_close(pb, pa, "fused vs separate normalisation", mx=2e-2, mean=3e-3)
-    for i in range(B):
-        for u, v in zip(mb[i][1], ma[i][1]):
-            assert abs(u - v) <= 1e-2 * abs(v) + 1e-5, (i, mb[i], ma[i])
-
-
-def _walk(layer):
-    """Every leaf layer under a Seq / Par."""
-    if isinstance(layer, engine.Seq):
-        for l in layer.layers:
-            yield from _walk(l)
-    elif isinstance(layer, engine.Par):
-        for b in layer.branches:
-            yield from _walk(b)
-    else:
-        yield layer
-
-
-def test_training_plan_with_the_pool_branch_folded(monkeypatch):
-    """RIED_POOL_FOLD_TRAIN=1: avg_pool + 1x1 of the pool branches as one 3x3 convolution also in training plans (off
-    by default: measured slower).  Same step as the default plan up to bf16 rounding (the pooled tensor is no longer
-    rounded; the weights are divided by nine before rounding)."""
-    B, H = 4, 64
-    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
-    x, y = synth_batch(B, H, seed=97)
-    base = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False)
-    monkeypatch.setenv("RIED_POOL_FOLD_TRAIN", "1")
-    fold = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False)
-    assert any(isinstance(l, engine.ConvBN) and l.core.pool_fold for m in fold.G.body.layers for l in _walk(m))
-    assert not any(isinstance(l, engine.ConvBN) and l.core.pool_fold for m in base.G.body.layers for l in _walk(m))
-    for ts in (base, fold):
-        ts.step(x.to(DEV), y.to(DEV))
-    torch.cuda.synchronize()
-    a, b = base.losses(), fold.losses()
-    for k in ("dloss1", "dloss2", "gloss", "vgg", "dssim", "gen"):
-        assert abs(a[k] - b[k]) <= 1e-2 * abs(a[k]) + 1e-4, (k, a[k], b[k])
-    act_close(fold.G.out.cpu(), base.G.out.cpu(), "prediction", mx=2e-2, mean=3e-3)
-    # the folded weights' gradients are the nine taps' sum over nine: a wrong scale shows in the norm ratio, a missing
-    # tap in the cosine (these tensors sit in front of a BatchNorm and are small, so rounding alone costs ~0.15 of it)
-    for k in ("layer_block_1.0.branch_pool.conv.weight", "layer_block_3.0.branch_pool.conv.weight"):
-        grad_close(fold.gs.g[k].cpu(), base.gs.g[k].cpu(), "G " + k, cos=0.7, ratio=0.35)
-    gf = torch.cat([fold.gs.g[k].float().flatten() for k in sorted(fold.gs.g)]).cpu()
-    gb = torch.cat([base.gs.g[k].float().flatten() for k in sorted(base.gs.g)]).cpu()
-    grad_close(gf, gb, "all generator gradients", cos=0.97, ratio=0.1)

@@ -112,3 +112,37 @@ def test_restore_into_a_lookahead_plan(tmp_path):
     for k in la:
         assert abs(la[k] - lb[k]) <= 5e-3 * abs(la[k]) + 1e-6, (k, la[k], lb[k])
     assert torch.allclose(a.gs.flat, b.gs.flat, rtol=0, atol=2.5e-4)
+
+
+def test_lookahead_plan_resumes_without_a_second_power_iteration(tmp_path, monkeypatch):
+    """A checkpoint written after a look-ahead step holds spectral-norm vectors that already include the next step's
+    power iteration; the file says so (key `ried_d_prepared`, beside the reference's seven keys) and a look-ahead
+    plan restored from it rebuilds sigma and the packed weights from those vectors without iterating again: the
+    resumed run takes the same next step as the uninterrupted one."""
+    from reid_gan_amd import engine
+    monkeypatch.setattr(engine, "BN_FOLD", False)        # fixed-order reductions: the runs must agree closely
+    B, H = 4, 64
+    gsd, dsd, vgg = synth_state(_spec("G"), 101), synth_state(_spec("D"), 202), synth_vgg()
+    x, y = (t.to(DEV) for t in synth_batch(B, H, seed=3))
+    a = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False, lookahead=True)
+    a.step(x, y)
+    path = str(tmp_path / "ckpt.pth.tar")
+    C.save_checkpoint(path, a, epoch=1, total_iters=1)
+    ck = C.load_checkpoint(path)
+    assert ck.get("ried_d_prepared") is True
+    b = TrainStep(synth_state(_spec("G"), 7), synth_state(_spec("D"), 8), vgg, B, H, H, lr=1e-4, use_graph=False,
+                  lookahead=True)
+    C.restore(b, ck)
+    assert b._resume_prepared and not b._d_ready
+    a.step(x, y); b.step(x, y)
+    torch.cuda.synchronize()
+    for k in ("discriminator_net.0.conv2d.weight_u", "discriminator_net.6.conv2d.weight_v"):
+        assert torch.allclose(a.ds.b[k], b.ds.b[k], rtol=0, atol=1e-6), k      # same number of power iterations
+    la, lb = a.losses(), b.losses()
+    for k in la:
+        assert abs(la[k] - lb[k]) <= 1e-3 * abs(la[k]) + 1e-6, (k, la[k], lb[k])
+    # a plain plan written from has no such key
+    p = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False)
+    p.step(x, y)
+    C.save_checkpoint(path, p, epoch=1, total_iters=1)
+    assert "ried_d_prepared" not in C.load_checkpoint(path)
