@@ -57,6 +57,16 @@ SC_DLOSS1, SC_DLOSS2 = 10, 11
 # chain their memory pools, the last captured must die first), synchronise - and never from the garbage collector.
 _RETAINED_GRAPHS = []
 
+# Stream-capture mode of every capture made here.  In the runtime's default ("global") mode a call that capture does
+# not allow - an event query, a host allocation - made by ANY thread of the process while a capture is open fails in
+# that thread and invalidates the capture.  RCCL's watchdog thread polls the events of finished collectives with
+# exactly such queries: a capture begun right after the warm-up step's all-reduces was invalidated ("operation failed
+# due to a previous error during capture") and the watchdog thread, whose query had failed, ended the process with
+# std::terminate (SIGABRT on a secondary thread; native frames in libtorch_hip.so under a std::thread).  A loader's
+# pinned-memory thread is another such caller.  "thread_local" confines the check to the capturing thread, which is
+# the only one that launches into the captured streams.
+CAPTURE_MODE = "thread_local"
+
 
 def _free_graphs() -> bool:
     return bool(os.environ.get("RIED_FREE_GRAPHS"))
@@ -515,7 +525,7 @@ class TrainStep:
         done = False
         while not done:
             g = _retain(torch.cuda.CUDAGraph())
-            with torch.cuda.graph(g, pool=pool):
+            with torch.cuda.graph(g, pool=pool, capture_error_mode=CAPTURE_MODE):
                 t = None
                 while True:
                     try:
@@ -605,7 +615,7 @@ class InferenceEngine:
                 for k, v in snap.items():
                     self.gs.b[k].copy_(v)
                 self.graph = _retain(torch.cuda.CUDAGraph())
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
                     self._body()
             self.graph.replay()
         return self.G.out, self.sums
@@ -695,7 +705,7 @@ class SliceInference(InferenceEngine):
                 self._body()                       # loads every kernel before the capture
                 torch.cuda.synchronize()
                 self.graph = _retain(torch.cuda.CUDAGraph())
-                with torch.cuda.graph(self.graph):
+                with torch.cuda.graph(self.graph, capture_error_mode=CAPTURE_MODE):
                     self._body()
             self.graph.replay()
         return self.pred, self.sums

@@ -1,6 +1,8 @@
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -8,7 +10,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-DP_OUTDIR = os.path.join(ROOT, "gpurun_out", "dp_children")
+# The rank processes write their results (whole flat parameter buffers: some 200 MB) outside the tree; their logs
+# and exit codes are copied to gpurun_out/dp_children when the results are collected.
+DP_OUTDIR = os.path.join(tempfile.gettempdir(), f"ried_dp_children_{os.getpid()}")
+DP_LOGDIR = os.path.join(ROOT, "gpurun_out", "dp_children")
 _dp_launcher = None
 
 
@@ -73,6 +78,10 @@ def dp_results():
     except subprocess.TimeoutExpired:
         _dp_launcher.kill()
         pytest.fail("the multi-rank launcher did not finish within 900 s: " + DP_OUTDIR)
+    os.makedirs(DP_LOGDIR, exist_ok=True)
+    for f in os.listdir(DP_OUTDIR):
+        if not f.endswith(".npz"):
+            shutil.copy(os.path.join(DP_OUTDIR, f), os.path.join(DP_LOGDIR, f))
     return DP_OUTDIR
 
 

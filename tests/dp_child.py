@@ -126,6 +126,9 @@ def run_rank(name: str, rank: int, world: int, port: int, outdir: str):
             for k, v in ts.losses().items():
                 out[f"step{i}.loss.{k}"] = v
             out[f"step{i}.pred"] = ts.G.out.cpu().numpy()
+            if rank == 0 and i == 0:      # the averaged gradients of the first step (identical on every rank)
+                out["step0.g_grad"] = ts.gs.flat_grad.cpu().numpy()
+                out["step0.d_grad"] = ts.ds.flat_grad.cpu().numpy()
         out["n_graphs"] = 0 if ts.graphs is None else len(ts.graphs)
         out["g_flat"] = ts.gs.flat.cpu().numpy()
         out["d_flat"] = ts.ds.flat.cpu().numpy()

@@ -134,13 +134,28 @@ def test_lookahead_plan_resumes_without_a_second_power_iteration(tmp_path, monke
                   lookahead=True)
     C.restore(b, ck)
     assert b._resume_prepared and not b._d_ready
-    a.step(x, y); b.step(x, y)
+    # ... and a third plan restored from the same file with the key taken away: it iterates once more
+    c = TrainStep(synth_state(_spec("G"), 7), synth_state(_spec("D"), 8), vgg, B, H, H, lr=1e-4, use_graph=False,
+                  lookahead=True)
+    C.restore(c, {k: v for k, v in ck.items() if k != "ried_d_prepared"})
+    assert not c._resume_prepared
+    a.step(x, y); b.step(x, y); c.step(x, y)
     torch.cuda.synchronize()
+    # Same number of power iterations: the vectors agree up to the round-off of two runs whose reductions are not
+    # bit-reproducible (float atomics in the split weight gradients), 2e-3 absolute on unit vectors, and are at
+    # least five times closer than the run that iterated once more.
     for k in ("discriminator_net.0.conv2d.weight_u", "discriminator_net.6.conv2d.weight_v"):
-        assert torch.allclose(a.ds.b[k], b.ds.b[k], rtol=0, atol=1e-6), k      # same number of power iterations
+        d_ab = (a.ds.b[k] - b.ds.b[k]).abs().max().item()
+        d_ac = (a.ds.b[k] - c.ds.b[k]).abs().max().item()
+        assert d_ab <= 2e-3 and 5 * d_ab < d_ac, (k, d_ab, d_ac)
+    # Losses: what is computed before the step's first Adam update agrees tightly; dloss2 and the adversarial term
+    # come after the discriminator's first update, which moves every weight by about lr whatever the size of its
+    # gradient (Adam's first steps), so round-off in a gradient's sign shows there: the tolerance of the other
+    # restore tests.
     la, lb = a.losses(), b.losses()
     for k in la:
-        assert abs(la[k] - lb[k]) <= 1e-3 * abs(la[k]) + 1e-6, (k, la[k], lb[k])
+        tol = 1e-2 if k in ("dloss2", "gen", "gloss") else 1e-3
+        assert abs(la[k] - lb[k]) <= tol * abs(la[k]) + 1e-6, (k, la[k], lb[k])
     # a plain plan written from has no such key
     p = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False)
     p.step(x, y)
