@@ -33,6 +33,7 @@ import torch
 
 PEAK_MFMA_BF16 = 2.5e15        # dense bf16 MFMA peak of one MI355X, FLOP/s
 PEAK_HBM = 8.0e12              # HBM3E peak, B/s
+G_CONV_OUT_PER_PIXEL = 716288 / 4096.0   # conv + deconv output elements of RIGAN per input pixel
 FLOP_PER_PATCH_64 = 17.716e9   # 3 G + 13 D + 3 VGG forward-equivalents at 64x64 (needed work only)
 
 
@@ -228,7 +229,22 @@ def infer_bench(steps=5, warmup=2, batch=32, size=512, slice_mode=False):
                              "runs a batch-1 loader); 'value' above is the generator applied to the whole batch"}
         del se
         torch.cuda.empty_cache()
+    # HBM roofline of the whole pass.  Algorithmic bytes: every convolution / transposed-convolution output of the
+    # generator written and read once in bf16 (174.875 output elements per input pixel: 716,288 per 64 x 64 image,
+    # the same at every size), the fp32 input slice read once, and the metrics' one read of x, y and the prediction
+    # (12 B per pixel).  BatchNorm passes, pools, upsampling and concatenation are not in it: they are what an ideal
+    # implementation folds away.  `traffic`: HBM bytes per batch from the committed counter passes
+    # (tools/pmc_infer.py over tools/infer_prof.py).
+    bytes_pass = batch * size * size * (G_CONV_OUT_PER_PIXEL * 4.0 + 4.0 + 12.0)
+    traffic = None
+    f = os.path.join(ROOT, "profiles", "r03_pmc_infer_traffic.json")
+    if os.path.exists(f) and batch == 32 and size == 512:
+        traffic = json.load(open(f))["traffic_MB_per_batch"] * 1e6
+    roof = {"bound": "hbm", "achieved": bytes_pass / (ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+            "frac": bytes_pass / (ms * 1e-3) / PEAK_HBM, "algorithmic_bytes_per_batch": bytes_pass,
+            "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else traffic / bytes_pass}
     return {"metric": "512x512 slices/sec (generator inference + SSIM/PSNR/RMSE)", "value": batch / (ms * 1e-3),
+            "roofline": roof,
             "per_slice_statistics": per_slice,
             "unit": "slices/s", "ms_per_batch": ms, "batch": batch,
             "mfma_frac": batch / (ms * 1e-3) * 34.67e9 / PEAK_MFMA_BF16,
@@ -418,6 +434,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="prepare every step's targets inside that step (default on one GPU: at the end of the step before)")
+    ap.add_argument("--reseed-d", type=int, default=8,
+                    help="put the discriminator back to its initial state every that many steps (0: never), so that "
+                         "the hinge gates of DLoss stay open in the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
@@ -459,21 +478,40 @@ def main():
                 print(f"[rank {rank}] steps done {ts.steps_done}, segment {ts.segment}, exchange {ts.exchange}",
                       file=sys.stderr, flush=True)
         threading.Thread(target=watch, daemon=True).start()
-    x, y = synth_batch(args.batch, args.size, seed=1234 + rank)
-    ts.x.copy_(x.cuda())
-    ts.y.copy_(y.cuda())
+    # The regime the step trains in: NB resident batches rotate through step(x, y, y_next=...) - the call a
+    # prefetching loader makes, so a look-ahead plan finds every batch's targets announced - and the discriminator
+    # is put back to its initial state every --reseed-d steps: on synthetic data it separates target from
+    # prediction within five steps, after which both hinge gates of DLoss (batch means, src/loss.py:141-142) are
+    # closed and every discriminator gradient kernel would be multiplying exact zeros.
+    NB = 4
+    batches = [tuple(t.cuda() for t in synth_batch(args.batch, args.size, seed=1234 + rank + 1000 * i))
+               for i in range(NB)]
+    dsnap = ts.snapshot_discriminator() if args.reseed_d > 0 else None
+    counter = [0]
+
+    def one_step():
+        i = counter[0]
+        counter[0] += 1
+        if dsnap is not None and i % args.reseed_d == 0 and i > 0:
+            ts.reseed_discriminator(dsnap)
+        x, y = batches[i % NB]
+        if ts.lookahead:
+            ts.step(x, y, y_next=batches[(i + 1) % NB][1])
+        else:
+            ts.step(x, y)
+
     first = None
     for i in range(args.warmup):
-        ts.step()
-        if i == 0:        # the timed loop replays one batch, which the discriminator soon separates perfectly (its
-            first = ts.losses()      # hinge losses then read 0): the first step's values are the sanity signal
+        one_step()
+        if i == 0:
+            first = ts.losses()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        ts.step()
+        one_step()
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -483,7 +521,15 @@ def main():
         t = torch.tensor([dt], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
-    losses = ts.losses()
+    losses = ts.losses()                 # of the last timed step
+    # Are the hinge gates open in the timed pattern?  Untimed: the same loop goes on until the step after the next
+    # re-seed, whose losses are read (a host synchronisation the timed loop does not have).
+    gates = None
+    if dsnap is not None:
+        while (counter[0] - 1) % args.reseed_d != 1:
+            one_step()
+        gates = ts.losses()
+        assert gates["dloss1"] > 0.0 or gates["dloss2"] > 0.0, ("the hinge gates are closed right after a re-seed", gates)
     value = world * args.batch * args.steps / dt
     out = {
         "metric": "train patches/sec (G+D+VGG step)", "value": value, "unit": "patches/s", "n_gpus": world,
@@ -496,7 +542,9 @@ def main():
                    # every timed step does the whole step's work; with look-ahead the part that needs only the target
                    # batch (VGG target features, D's weight preparation and target-half pass) is the NEXT step's,
                    # run at the end of this one beside the generator backward
-                   "lookahead": ts.lookahead, "losses": losses, "losses_first_step": first},
+                   "lookahead": ts.lookahead, "resident_batches": NB, "announced_y_next": ts.lookahead,
+                   "d_reseed_every": args.reseed_d, "losses": losses, "losses_first_step": first,
+                   "losses_step_after_reseed": gates},
     }
     if args.size == 64:
         out["step_mfma_frac"] = value / world * FLOP_PER_PATCH_64 / PEAK_MFMA_BF16

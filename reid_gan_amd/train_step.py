@@ -456,6 +456,34 @@ class TrainStep:
         self._primed = self._d_ready = False
         self._resume_prepared = bool(d_prepared) and self.lookahead
 
+    def snapshot_discriminator(self):
+        """A device copy of everything the discriminator's training owns (weights, spectral-norm vectors, Adam
+        moments and step count), for reseed_discriminator()."""
+        st = self.ds
+        return {"flat": st.flat.clone(), "b": {k: v.clone() for k, v in st.b.items()},
+                "adam": (st.adam_m.clone(), st.adam_v.clone(), st.adam_step.clone())}
+
+    def reseed_discriminator(self, snap):
+        """Put the discriminator back to a snapshot between two steps (device copies, no host synchronisation).
+        DLoss is a hinge on the batch MEANS (src/loss.py:141-142): once the discriminator separates the batch both
+        gates close and its gradient is exactly zero until the generator catches up.  A benchmark that wants the
+        gates open - gradients with real values in every discriminator kernel - re-seeds the discriminator every few
+        steps.  A look-ahead plan redoes what it had prepared from the old weights (spectral norms, packed weights
+        and the pass over the next batch's targets; the VGG target features do not depend on the discriminator)."""
+        st = self.ds
+        st.flat.copy_(snap["flat"])
+        for k, v in snap["b"].items():
+            st.b[k].copy_(v)
+        for dst, src in zip((st.adam_m, st.adam_v, st.adam_step), snap["adam"]):
+            dst.copy_(src)
+        if self.lookahead and self._primed:
+            self.D.prepare()
+            if self.la_dreal:
+                self.D.forward_images(self.d_in, 0, self.B)
+            self._d_ready = True
+        else:
+            self._d_ready = False
+
     @staticmethod
     def _key(t: torch.Tensor):
         return (t.data_ptr(), t._version, tuple(t.shape))
