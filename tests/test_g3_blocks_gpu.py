@@ -147,3 +147,53 @@ def test_block_against_golden_and_oracle(golden_dir, name):
 def test_block_larger_shapes(name, N, hw):
     """Shapes that make the weight-gradient K loop run several tiles per split and several splits."""
     _run_block(name, N, hw)
+
+
+# The blocks of the generator at the shapes of the benchmarked training step (batch 128 of 64 x 64 patches: maps of
+# 16 x 16, 8 x 8 and 4 x 4 inside the blocks, 32 x 32 for conv2 / deconv2), where the plans take other tiles, split-K
+# factors and fold rows than the two-image cases above: same tolerances.
+BENCH_SHAPES = [("basic_conv_3x3s2", 32), ("basic_deconv_4x4s2", 32), ("inception_a_64", 16), ("inception_a_256", 16),
+                ("inception_b_enc", 16), ("inception_b_dec", 8), ("inception_c_256", 8), ("inception_c_512", 8),
+                ("inception_d_enc", 8), ("inception_d_dec", 4), ("inception_e_512", 4)]
+
+
+def _plan_features(name, N, hw):
+    """(Par objects, ConvBN layers) of the block's plan at that shape (no kernels run)."""
+    _, build, cin, _, (cout, _) = BLOCKS[name]
+    bi = ORDER.index(name)
+    spec = _Stripped(spec_mode=True)
+    with torch.no_grad():
+        ho = BLOCKS[name][0](spec, torch.zeros(1, cin, hw, hw)).shape[-1]
+    st = State({"." + k: v for k, v in synth_state([(n, s) for n, s, _ in spec.spec], 300 + bi).items()}, DEV)
+    ctx = Ctx(st, DEV, grads=True, training=True)
+    plan = build(ctx, Slot(ctx.act(N, hw, hw, cin)), Slot(ctx.act(N, ho, ho, cout)))
+    ctx.finalize()
+    pars, convs = [], []
+
+    def walk(l):
+        if isinstance(l, engine.Seq):
+            for q in l.layers:
+                walk(q)
+        elif isinstance(l, engine.Par):
+            pars.append(l)
+            for b in l.branches:
+                walk(b)
+        elif isinstance(l, engine.InputGradGroup):
+            for m in l.members:
+                walk(m)
+        elif isinstance(l, engine.ConvBN):
+            convs.append(l)
+    walk(plan)
+    return pars, convs
+
+
+@pytest.mark.parametrize("name,hw", BENCH_SHAPES)
+def test_block_at_the_benchmark_batch(name, hw):
+    N = 128
+    if name.startswith("inception"):
+        pars, convs = _plan_features(name, N, hw)
+        # the code paths of the benchmarked plan are the ones under test: level-wise job tables for the branches,
+        # BatchNorm sums folded with atomics forward and backward (no finalize / finish launches)
+        assert pars and all(p.levels is not None for p in pars), name
+        assert convs and all(c.sliced and c.bwd_fold for c in convs), name
+    _run_block(name, N, hw)
