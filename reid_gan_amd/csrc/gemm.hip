@@ -782,9 +782,8 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned byt
 
 // NT threads: 256 (2 x 2 waves) or 512 (2 x 4 waves: twice the pixels per block for the same weight traffic).
 // (bx, by) of (nbx, nby): the block's place in the problem's own grid (the launch grid, or a job's share of one)
-template <int BM, int BN, int NST, int NT, bool XF = false>
+template <int BM, int BN, int NST, int NT>
 __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int by, int nbx, int nby, char* smem) {
-  static_assert(!XF || NST == 3, "the input transform works one stage ahead of the matrix products");
   constexpr int WN = NT / 128;                        // waves along the pixel axis
   constexpr int RPP = NT / 8;                         // rows per DMA pass (8 lanes = one 128-byte row)
   constexpr int TM = BM / 32, TN = BN / (16 * WN);
@@ -847,19 +846,6 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
 
   char* const lds_wave = smem + wave * 1024;            // + i * NT * 16 per row pass, + BM * 128 for B
   const unsigned ldx2 = (unsigned)X.ld * 2u;
-  // input transform: per-channel (scale, shift) table behind the stages; the chunk state of the stage in flight
-  float* const xf_ab = reinterpret_cast<float*>(smem + NST * STAGE);      // [2][K]
-  int xf_c = 0, xf_c_prev = 0;           // chunk state of the newest stage issued and of the one before it
-  unsigned xf_bad = 0, xf_bad_prev = 0;
-  if constexpr (XF) {
-    for (int ch = tid; ch < P.K; ch += NT) {
-      const float a = P.xf_gamma[ch] * P.xf_save[P.K + ch];
-      xf_ab[ch] = a;
-      xf_ab[P.K + ch] = P.xf_beta[ch] - P.xf_save[ch] * a;
-    }
-    __syncthreads();
-  }
-
   // Offsets are 16-byte aligned, so OR-ing GLDS_OOB into one leaves it out of range whatever its value: validity
   // is carried as a mask (0 or GLDS_OOB) and never as a branch around a load, which keeps the number of DMA
   // instructions per stage exact for the counted waits below.
@@ -872,13 +858,11 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
     for (int i = 0; i < NLA; ++i) glds16(rsA, (wrow[i] + wk) | inval, dst + i * (NT * 16));
     const int dpx = dir * (ti * X.W + tj);
     const unsigned cb = (unsigned)c * 16u;
-    if constexpr (XF) { xf_c_prev = xf_c; xf_bad_prev = xf_bad; xf_c = c * 8; xf_bad = 0; }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
       int hi = gy[i] + dir * ti, wi = gx[i] + dir * tj;
       unsigned bad = ((unsigned)hi < (unsigned)X.H && (unsigned)wi < (unsigned)X.W) ? 0u : GLDS_OOB;
       glds16(rsB, ((unsigned)(pix[i] + dpx) * ldx2 + cb) | bad | inval, dst + BM * 128 + i * (NT * 16));
-      if constexpr (XF) xf_bad |= ((bad | inval) ? 1u : 0u) << i;
     }
     c += 8;
     while (c >= CPT) {
@@ -913,41 +897,9 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
   };
 
-  // Input transform: this lane's own chunks of stage `buf` have landed; normalise and activate them in place (the
-  // chunks of padding pixels and of the K tail hold the DMA's zeros and stay zero).  It runs one stage AHEAD of the
-  // matrix products, right after they are issued, so the vector work overlaps the matrix pipe; the next barrier
-  // publishes the result.
-  auto xf_stage = [&](int buf) {
-    float sc[8], sh[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { sc[q] = xf_ab[xf_c_prev + q]; sh[q] = xf_ab[P.K + xf_c_prev + q]; }
-    char* const own = lds_wave + buf * STAGE + BM * 128 + lane * 16;
-#pragma unroll
-    for (int i = 0; i < NLB; ++i) {
-      if (!((xf_bad_prev >> i) & 1u)) {
-        u32x4 v = *reinterpret_cast<u32x4*>(own + i * (NT * 16));
-        float f0 = bflo(v[0]) * sc[0] + sh[0], f1 = bfhi(v[0]) * sc[1] + sh[1];
-        float f2 = bflo(v[1]) * sc[2] + sh[2], f3 = bfhi(v[1]) * sc[3] + sh[3];
-        float f4 = bflo(v[2]) * sc[4] + sh[4], f5 = bfhi(v[2]) * sc[5] + sh[5];
-        float f6 = bflo(v[3]) * sc[6] + sh[6], f7 = bfhi(v[3]) * sc[7] + sh[7];
-        if (P.xf_act == 1) {
-          f0 = fmaxf(f0, 0.f); f1 = fmaxf(f1, 0.f); f2 = fmaxf(f2, 0.f); f3 = fmaxf(f3, 0.f);
-          f4 = fmaxf(f4, 0.f); f5 = fmaxf(f5, 0.f); f6 = fmaxf(f6, 0.f); f7 = fmaxf(f7, 0.f);
-        }
-        *reinterpret_cast<u32x4*>(own + i * (NT * 16)) =
-            u32x4{pack2bf(f0, f1), pack2bf(f2, f3), pack2bf(f4, f5), pack2bf(f6, f7)};
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  };
-
   // prologue: NST-1 stages in flight (stages past the end of K fetch zeros: uniform counts)
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s) issue(s);
-  if constexpr (XF) {       // stage 0 has no earlier step to be transformed in
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");
-    xf_stage(0);
-  }
   int rd = 0, wr = NST - 1;
   for (int step = 0; step < nsteps; ++step) {
     // the DMA of stage `step` has landed for this wave's loads once at most NST-2 later stages are outstanding;
@@ -961,10 +913,6 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
     mfmas(1);
     rd = rd + 1 == NST ? 0 : rd + 1;
     wr = wr + 1 == NST ? 0 : wr + 1;
-    if constexpr (XF) {       // the stage the NEXT step consumes (issued one step ago) while the matrix pipe works
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");
-      xf_stage(rd);
-    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may outlive the block or race the epilogue
   __builtin_amdgcn_s_barrier();
@@ -982,12 +930,227 @@ __global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
   conv_glds_body<BM, BN, NST, NT>(P, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
 }
 
-// The same with the input transform (GemmParams::xf_*); K <= XF_MAX_K input channels.
+// ---------------------------------------------------------------------------
+// The same convolution with an input transform (GemmParams::xf_*): the pixel operand is the RAW output of a
+// BasicConv2d layer's convolution and is normalised (train-mode BatchNorm) and activated on its way IN:
+// global -> registers -> scale, shift, ReLU -> LDS.  The weights keep the LDS-DMA path.  Compared with transforming
+// the operand in place in LDS (measured: +70 % on the consumer, more than the apply pass it saves) this adds no LDS
+// traffic: the register path's one ds_write_b128 per chunk replaces the DMA's write.
+//
+// Rings: three weight stages (small: BM x 128 bytes each), two pixel stages in LDS and two register sets of pixel
+// chunks.  In step s the loads of stage s + 2 are issued (weights by DMA, pixels into the register set that stage s
+// vacated), the products of stage s run, and then the pixels of stage s + 1 - loaded one step earlier - are
+// transformed and written to the LDS stage that step s - 1 read; the barrier at the top of step s + 1 publishes
+// them.  Loads complete in order, so both waits are counted: everything but the newest issue group.
+// Padding pixels, rows past the problem and the K tail load zeros (out-of-range buffer offsets) and must STAY zero
+// (zero padding pads the activated tensor): one validity bit per chunk.  K <= XF_MAX_K input channels.
+// ---------------------------------------------------------------------------
 #define XF_MAX_K 1024
-template <int BM, int BN, int NT = 256>
+template <int BM, int BN, int NT>
 __global__ __launch_bounds__(NT) void conv_glds_xf_kernel(const GemmParams P) {
-  __shared__ __attribute__((aligned(1024))) char smem[3 * (BM + BN) * 128 + 2 * XF_MAX_K * 4];
-  conv_glds_body<BM, BN, 3, NT, true>(P, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
+  constexpr int WN = NT / 128;
+  constexpr int RPP = NT / 8;
+  constexpr int TM = BM / 32, TN = BN / (16 * WN);
+  constexpr int NLA = BM / RPP, NLB = BN / RPP;
+  constexpr int ASTAGE = BM * 128, BSTAGE = BN * 128;
+  constexpr int RINGS = 3 * ASTAGE + 2 * BSTAGE;
+  __shared__ __attribute__((aligned(1024))) char smem[RINGS + 2 * XF_MAX_K * 4];
+  char* const smemB = smem + 3 * ASTAGE;
+  float* const xf_ab = reinterpret_cast<float*>(smem + RINGS);      // [2][K]: scale, shift per input channel
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int nbx = gridDim.x, by = blockIdx.y;
+  int bid = blockIdx.x;
+  {      // XCD-aware order, as in conv_glds_body
+    const int nwg = nbx, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid % P.tiles_m, tn = bid / P.tiles_m;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const GemmOperand& X = P.B;
+  int pa = 0, pb = 0, r0 = 0, s0 = 0, ti_n = X.kh, tj_n = X.kw;
+  const int dir = X.transposed ? -1 : 1;
+  if (X.transposed) {
+    pa = by / X.sw; pb = by % X.sw;
+    r0 = (pa + X.ph) % X.sh; s0 = (pb + X.pw) % X.sw;
+    ti_n = (X.kh - r0 + X.sh - 1) / X.sh; tj_n = (X.kw - s0 + X.sw - 1) / X.sw;
+  }
+  const int rstep = X.transposed ? X.sh : 1, sstep = X.transposed ? X.sw : 1;
+  const int CPT = P.K >> 3;
+  const int nsteps = (ti_n * tj_n * CPT + 7) >> 3;
+
+  for (int ch = tid; ch < P.K; ch += NT) {
+    const float a = P.xf_gamma[ch] * P.xf_save[P.K + ch];
+    xf_ab[ch] = a;
+    xf_ab[P.K + ch] = P.xf_beta[ch] - P.xf_save[ch] * a;
+  }
+
+  const int rowp = tid >> 3;
+  const int kq = (tid & 7) ^ (rowp & 7);
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A.p, 0, P.A_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B.p, 0, P.B_bytes, 0x00020000);
+  unsigned wrow[NLA];
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) {
+    int m = m0 + i * RPP + rowp;
+    wrow[i] = m < P.M ? (unsigned)m * (unsigned)P.A.ld * 2u : GLDS_OOB;
+  }
+  int gy[NLB], gx[NLB], pix[NLB];
+  const int hw = X.Ho * X.Wo;
+  const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)X.Wo;
+#pragma unroll
+  for (int i = 0; i < NLB; ++i) {
+    int n = n0 + i * RPP + rowp;
+    int rem, ox;
+    int img = fast_div(n, hw, inv_hw, rem);
+    int oy = fast_div(rem, X.Wo, inv_wo, ox);
+    if (X.transposed) { gy[i] = oy + (pa + X.ph - r0) / X.sh; gx[i] = ox + (pb + X.pw - s0) / X.sw; }
+    else              { gy[i] = oy * X.sh - X.ph;             gx[i] = ox * X.sw - X.pw; }
+    pix[i] = (img * X.H + gy[i]) * X.W + gx[i];
+    if (n >= P.N) gy[i] = -(1 << 24);
+  }
+  int c, ti, tj;
+  { int tap = kq / CPT; c = kq - tap * CPT; ti = tap / tj_n; tj = tap - ti * tj_n; }
+
+  char* const ldsA_wave = smem + wave * 1024;
+  char* const ldsB_own = smemB + wave * 1024 + lane * 16;      // where the DMA would have put this lane's chunk
+  const unsigned ldx2 = (unsigned)X.ld * 2u;
+
+  u32x4 rb[2][NLB];                 // pixel chunks in flight: set (stage & 1)
+  int rc[2] = {0, 0};               // first input channel of the set's chunks
+  unsigned rok[2] = {0u, 0u};       // bit i: chunk i is a real pixel (not padding, edge or K tail)
+
+  // issue the loads of the next K stage: weights by DMA into ring slot abuf, pixels into register set SET
+  auto issue = [&](int abuf, auto SETC) {
+    constexpr int SET = decltype(SETC)::value;
+    char* dst = ldsA_wave + abuf * ASTAGE;
+    unsigned inval = ti < ti_n ? 0u : GLDS_OOB;
+    asm volatile("" : "+v"(inval));
+    const unsigned wk = (unsigned)(((r0 + ti * rstep) * X.kw + (s0 + tj * sstep)) * P.K + c * 8) * 2u;
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) glds16(rsA, (wrow[i] + wk) | inval, dst + i * (NT * 16));
+    const int dpx = dir * (ti * X.W + tj);
+    const unsigned cb = (unsigned)c * 16u;
+    rc[SET] = c * 8;
+    unsigned ok = 0u;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      int hi = gy[i] + dir * ti, wi = gx[i] + dir * tj;
+      unsigned bad = ((unsigned)hi < (unsigned)X.H && (unsigned)wi < (unsigned)X.W) ? 0u : GLDS_OOB;
+      rb[SET][i] = __builtin_amdgcn_raw_buffer_load_b128(rsB, (int)(((unsigned)(pix[i] + dpx) * ldx2 + cb) | bad | inval),
+                                                         0, 0);
+      ok |= ((bad | inval) ? 0u : 1u) << i;
+    }
+    rok[SET] = ok;
+    c += 8;
+    while (c >= CPT) {
+      c -= CPT;
+      if (++tj == tj_n) { tj = 0; ++ti; }
+    }
+  };
+
+  // normalise + activate register set SET and store it as pixel stage SET of the LDS ring
+  auto xf_store = [&](auto SETC) {
+    constexpr int SET = decltype(SETC)::value;
+    float sc[8], sh[8];
+    const int c0 = rc[SET] < P.K ? rc[SET] : 0;       // (K tail of a stage past the end: chunks are invalid anyway)
+#pragma unroll
+    for (int q = 0; q < 8; q += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xf_ab + c0 + q);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(xf_ab + P.K + c0 + q);
+      sc[q] = a[0]; sc[q + 1] = a[1]; sc[q + 2] = a[2]; sc[q + 3] = a[3];
+      sh[q] = b[0]; sh[q + 1] = b[1]; sh[q + 2] = b[2]; sh[q + 3] = b[3];
+    }
+    char* const own = ldsB_own + SET * BSTAGE;
+    const bool relu = P.xf_act == 1;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      u32x4 v = rb[SET][i];
+      float f[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { f[2 * q] = bflo(v[q]) * sc[2 * q] + sh[2 * q]; f[2 * q + 1] = bfhi(v[q]) * sc[2 * q + 1] + sh[2 * q + 1]; }
+      if (relu) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = fmaxf(f[q], 0.f);
+      }
+      u32x4 o = u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+      if (!((rok[SET] >> i) & 1u)) o = u32x4{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4*>(own + i * (NT * 16)) = o;
+    }
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int frow = (lane & 15) * 128;
+  const int sw0 = (((lane >> 4)) ^ (lane & 7)) << 4, sw1 = ((4 + (lane >> 4)) ^ (lane & 7)) << 4;
+  bf16x8_t fa[2][TM], fb[2][TN];
+  auto load_frags = [&](int abuf, int bbuf, int ks) {
+    const char* sa = smem + abuf * ASTAGE + wm * (BM / 2) * 128 + frow;
+    const char* sb = smemB + bbuf * BSTAGE + wn * (BN / WN) * 128 + frow;
+    const int sw = ks ? sw1 : sw0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[ks][i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 2048 + sw);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[ks][j] = *reinterpret_cast<const bf16x8_t*>(sb + j * 2048 + sw);
+  };
+  auto mfmas = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // prologue: stages 0 and 1 in flight; stage 0's pixels transformed into LDS (the table first: it was written above)
+  issue(0, S0{});
+  issue(1, S1{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // the scale / shift table is complete
+  __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");
+  xf_store(S0{});
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  int ard = 0, awr = 2;             // weight ring: slot read this step, slot filled this step
+  auto step = [&](auto CURC) {
+    constexpr int CUR = decltype(CURC)::value;          // pixel stage / register set of this step: step & 1
+    using NXT = std::integral_constant<int, CUR ^ 1>;
+    // stage s: weights landed once only the newest issue group is outstanding; the barrier extends that to every
+    // wave's DMA and publishes the pixel stage written at the end of the previous step
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");
+    __builtin_amdgcn_s_barrier();
+    load_frags(ard, CUR, 0);
+    issue(awr, CURC);                                   // stage s + 2: register set CUR is free (stored last step)
+    load_frags(ard, CUR, 1);
+    mfmas(0);
+    mfmas(1);
+    ard = ard == 2 ? 0 : ard + 1;
+    awr = awr == 2 ? 0 : awr + 1;
+    // stage s + 1's pixels (issued one step ago) -> LDS stage CUR ^ 1, which step s - 1 read (all waves are past
+    // this step's barrier, so those reads have retired)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLA + NLB) : "memory");
+    xf_store(NXT{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+  for (int s = 0; s < nsteps; s += 2) {
+    step(S0{});
+    if (s + 1 < nsteps) step(S1{});
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (P.E.staged)
+    gemm_epilogue_staged<BM, BN, WN, RINGS>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, nbx / P.tiles_m, by, smem);
+  else
+    gemm_epilogue<BM, BN, false, WN>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, 0, nbx / P.tiles_m, by, 0,
+                                     nbx * gridDim.y, smem);
 }
 
 // Job-table form: several convolutions that do not depend on each other (the same-depth layers of an Inception
@@ -1857,11 +2020,10 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                  "ried_conv2d: operand larger than 4 GiB");
   P.A_bytes = (unsigned)a_bytes; P.B_bytes = (unsigned)b_bytes;
   ConvTile t = choose_conv_tile(Cout, npix, phases, conv_ksteps(Cin, kh, kw, sh, sw, transposed), kh * kw);
-  if (xf) {           // only the general kernel transforms its input, with two LDS stages
+  if (xf) {           // only the general kernel transforms its input (register-staged pixel operand)
     RIED_CHECK_ARG(xf->save && xf->gamma && xf->beta && Cin <= XF_MAX_K && !job && !fin,
                    "ried_conv2d_xf: bad transform arguments (Cin=%d, at most %d)", Cin, XF_MAX_K);
     P.xf_save = xf->save; P.xf_gamma = xf->gamma; P.xf_beta = xf->beta; P.xf_act = xf->act;
-    t.nst = 3;
   }
   int* const which = job ? job->which : nullptr;
   if (job && !which) {

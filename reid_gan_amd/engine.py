@@ -1217,13 +1217,18 @@ def _chain(ctx: Ctx, seq: Seq, prefix: str, specs, xin: Slot, out: Slot, deconv=
     return cur
 
 
-# Off unless RIED_XF_FUSE=1.  Measured on 32 slices of 512 x 512: the consumers' launches get 40-45 us slower each
-# (62 -> 108 us, with the transform between the DMA wait and the barrier or one stage ahead of the products on
-# three LDS stages) while the apply pass they replace took 37 us: 5.29 -> 5.89 ms per batch.  The cause is LDS
-# bandwidth: per stage a 64 x 256 block already moves 136 KB through LDS (DMA writes + fragment reads, ~1060 clocks
-# against ~1020 of matrix work), and reading and rewriting the pixel operand in place adds 128 KB.  A form that pays
-# would normalise on the way IN (global -> registers -> LDS: no extra LDS traffic), at the price of the LDS-DMA path.
-XF_FUSE = bool(os.environ.get("RIED_XF_FUSE"))
+# The consumer of an inner layer can apply that layer's BatchNorm + ReLU to its operand on the way in (ops.conv2d_xf:
+# global -> registers -> scale, shift, ReLU -> LDS), so that the normalised tensor is never written or read.  The
+# general convolution kernel fetches its pixel operand once per tap, so the transform is repeated per tap as well
+# and the kernel becomes vector-arithmetic bound: measured alone (tools/xf_bench.py, 32 slices of 512 x 512), a
+# stride-1 3 x 3 or 1 x 7 consumer takes 1.5-2.2x as long as the plain kernel (52 -> 117 us where the apply pass it
+# saves takes 14 us), a stride-2 3 x 3 consumer - 2.25 taps per operand pixel - breaks even or wins (45 -> 41 us,
+# 22 -> 19 us for apply + convolution).  Whole batch: 5.13 ms without, 5.105 ms with the stride-2 consumers only,
+# 5.74 ms with every consumer.  So: stride-2 consumers by default (RIED_XF_FUSE=0: none, =1: all).  An earlier
+# form that transformed the operand in place in LDS cost the consumers 40-45 us each (LDS bandwidth).  Results are
+# bit-identical to apply + convolution (same fp32 scale / shift, same rounding to bf16).
+XF_FUSE_MODE = os.environ.get("RIED_XF_FUSE", "s2")
+XF_FUSE = XF_FUSE_MODE not in ("", "0")
 
 
 def _xf_consumer_ok(ctx: Ctx, spec, deconv: bool, H: int, W: int) -> bool:
@@ -1235,6 +1240,8 @@ def _xf_consumer_ok(ctx: Ctx, spec, deconv: bool, H: int, W: int) -> bool:
     _, cin, cout, k, s, p = spec
     (kh, kw), (sh, sw) = _pair(k), _pair(s)
     if cin > 1024:
+        return False
+    if XF_FUSE_MODE == "s2" and (deconv or sh != 2):      # stride-2 consumers only: each operand pixel serves 2.25 taps
         return False
     if not deconv and (kh, kw, sh, sw) == (3, 3, 1, 1) and cin % 64 == 0 and H % 8 == 0 and W % 8 == 0:
         return False
