@@ -253,6 +253,12 @@ int ried_pool_fwd(const void* x, long long ldx, void* y, long long ldy, int nimg
                   ried_stream_t stream);
 int ried_pool_bwd(const void* x, long long ldx, const void* dy, long long lddy, void* dx, long long lddx, int nimg,
                   int H, int W, int C, int mode, int accumulate, int relu_mask, ried_stream_t stream);
+/* avg_pool2d(3,1,1) of the OUTPUT of a branch_pool 1x1 convolution (src/rinet.py:234,250-251; 320,344-345; 416,441-442:
+ * pool and bias-free 1x1 convolution commute) with the BatchNorm partial statistics of the pooled tensor:
+ * stats[ried_avgpool3_stats_rows(npix, C)][2][C], rows for ried_bn_finalize. */
+int ried_avgpool3_stats_rows(long long npix, int C);
+int ried_avgpool3_stats(const void* x, long long ldx, void* y, long long ldy, int nimg, int H, int W, int C,
+                        float* stats, ried_stream_t stream);
 /* ried_pool_bwd: dx (+)= pooled gradient (accumulate != 0 adds onto dx; max modes may overwrite instead);
  * relu_mask (max modes): the result is zeroed where x <= 0, the backward of the ReLU that produced x */ /* dx += */
 /* nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True) (src/rinet.py:266,361) */

@@ -1396,6 +1396,82 @@ extern "C" int ried_pool_fwd(const void* x, long long ldx, void* y, long long ld
   return RIED_OK;
 }
 
+// avg_pool2d(3, 1, 1) (count_include_pad) of a NARROW tensor together with the train-mode BatchNorm statistics of the
+// result.  avg_pool2d followed by a bias-free 1x1 convolution (the branch_pool of Inception A / C / E,
+// src/rinet.py:234,250-251; 320,344-345; 416,441-442) equals the convolution followed by the pool - both are linear
+// and zero padding commutes with a convolution that has no bias - and the convolution's output has 16-96 channels
+// where its input has 64-512: pooling AFTER the convolution moves 4-16x less data and lets the 1x1 layer ride in the
+// block's fused sibling convolution.  This kernel is that pool: y = avgpool3(x), and per block one row
+// stats[block][2][C] = column sums of y and y*y (fp32, before rounding to bf16), the partial rows ried_bn_finalize
+// reduces.  A thread owns one 8-channel chunk column and walks pixels; 256 / (C / 8) pixels per pass of the block.
+__global__ __launch_bounds__(EW_THREADS) void avgpool3_stats_kernel(const bf16_t* __restrict__ x, long long ldx,
+                                                                   bf16_t* __restrict__ y, long long ldy, int npix, int H,
+                                                                   int W, int C, float* __restrict__ stats) {
+  __shared__ float red[EW_THREADS][17];
+  const int CC = C >> 3, ppp = EW_THREADS / CC;            // pixels per pass
+  const int cc = threadIdx.x % CC, pp = threadIdx.x / CC, c = cc << 3;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  if (pp < ppp) {
+    for (int p = blockIdx.x * ppp + pp; p < npix; p += gridDim.x * ppp) {
+      const int wx = p % W, t = p / W, hy = t % H, n = t / H;
+      const bf16_t* xi = x + (long long)n * H * W * ldx + c;
+      float acc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+#pragma unroll
+      for (int r = -1; r <= 1; ++r) {
+#pragma unroll
+        for (int z = -1; z <= 1; ++z) {
+          const int hi = hy + r, wi = wx + z;
+          const bool ok = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+          const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
+          float f[8];
+          unpack8(ld8(xi + (long long)(hc * W + wc) * ldx), f);
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[q] += ok ? f[q] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { acc[q] *= (1.f / 9.f); s1[q] += acc[q]; s2[q] += acc[q] * acc[q]; }
+      st8(y + (long long)p * ldy + c, pack8(acc));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { red[threadIdx.x][q] = s1[q]; red[threadIdx.x][8 + q] = s2[q]; }
+  __syncthreads();
+  // thread t < 2 * C: statistic t / C (sum, sum of squares) of channel t % C over the block's pixel slots
+  for (int t = threadIdx.x; t < 2 * C; t += EW_THREADS) {
+    const int which = t / C, ch = t - which * C, k = ch >> 3, q = ch & 7;
+    float v = 0.f;
+    for (int j = 0; j < ppp; ++j) v += red[j * CC + k][which * 8 + q];
+    stats[(long long)blockIdx.x * 2 * C + t] = v;
+  }
+}
+
+// rows of the statistics buffer ([rows][2][C]) that ried_avgpool3_stats writes
+extern "C" int ried_avgpool3_stats_rows(long long npix, int C) {
+  const int ppp = EW_THREADS / (C / 8);
+  long long rows = (npix + (long long)ppp * 8 - 1) / ((long long)ppp * 8);          // about eight passes per block
+  return (int)(rows < 1 ? 1 : rows > 1024 ? 1024 : rows);
+}
+
+extern "C" int ried_avgpool3_stats(const void* x, long long ldx, void* y, long long ldy, int nimg, int H, int W, int C,
+                                   float* stats, hipStream_t stream) {
+  CHECK_VIEW("ried_avgpool3_stats", x, ldx, C);
+  CHECK_VIEW("ried_avgpool3_stats", y, ldy, C);
+  RIED_CHECK_ARG(stats && nimg > 0 && H > 0 && W > 0 && C >= 8 && C <= 8 * EW_THREADS,
+                 "ried_avgpool3_stats: bad arguments");
+  const long long npix = (long long)nimg * H * W;
+  RIED_CHECK_ARG(npix < (1ll << 31), "ried_avgpool3_stats: tensor too large");
+  const int rows = ried_avgpool3_stats_rows(npix, C);
+  hipLaunchKernelGGL(avgpool3_stats_kernel, dim3(rows), dim3(EW_THREADS), 0, stream, (const bf16_t*)x, ldx, (bf16_t*)y,
+                     ldy, (int)npix, H, W, C, stats);
+  RIED_CHECK_LAUNCH("ried_avgpool3_stats");
+  return RIED_OK;
+}
+
 // MaxPool2d(2, 2) backward (even H, W: the windows tile the input).  One thread owns one WINDOW chunk: it reads the
 // four inputs and the output gradient once and writes the four input gradients - every tensor exactly once.
 __global__ __launch_bounds__(EW_THREADS) void maxpool2_bwd_kernel(const bf16_t* __restrict__ x, long long ldx,

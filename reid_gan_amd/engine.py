@@ -515,13 +515,17 @@ class ConvBN:
     def __init__(self, ctx: Ctx, prefix: str, cin, cout, k, stride, pad, xin: Slot, out: Slot, deconv=False,
                  accumulate=False, need_dx=True, conv_key=None, bn_key=None, bias=False, act=1, shared=False,
                  wgrad_out: Optional[torch.Tensor] = None, defer_apply=False, pool_fold=False,
-                 xf_src: Optional["ConvBN"] = None):
+                 xf_src: Optional["ConvBN"] = None, post_pool=False):
         """bias / act / shared / wgrad_out serve the legacy networks (src/networks.py:466-542): a conv bias in front
         of the BatchNorm (train mode: it only shifts running_mean), the activation code of ops.bn_apply, layers
         applied several times per forward (BatchNorm and bias gradients then add onto the state's), and a
         private buffer for this use's weight gradient.  defer_apply (forward-only plans): the layer stops at the
         statistics (`save`); its consumer reads `raw` and applies the normalisation itself - xf_src names that
-        producer to the consumer, whose convolution then normalises its operand on the way through LDS."""
+        producer to the consumer, whose convolution then normalises its operand on the way through LDS.
+        post_pool (forward-only plans): the layer is the 1x1 convolution of a branch_pool (src/rinet.py:234,250-251 and
+        alike) whose avg_pool2d(3, 1, 1) is applied to the convolution's OUTPUT instead of its input - the two are
+        linear and commute (no bias; zero padding) - so the pool runs on cout instead of cin channels and the
+        convolution can ride in the block's sibling group: conv -> pool + statistics (ops.avgpool3_stats) -> BN."""
         self.ctx, self.prefix, self.lane = ctx, prefix, ctx.build_lane
         conv_key = conv_key or (prefix + (".deconv" if deconv else ".conv"))
         self.bn = bn_key or (prefix + ".bn")
@@ -542,6 +546,13 @@ class ConvBN:
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
         self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, cin, c.cout, c.kh, c.kw, c.sh, c.sw, deconv)
         self.defer_apply = defer_apply
+        self.post_pool = bool(post_pool)
+        if self.post_pool:
+            assert (not ctx.grads and not ctx.per_image and not bias and not defer_apply and not deconv
+                    and _pair(k) == (1, 1) and _pair(stride) == (1, 1))
+            self.praw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
+            self.prows = ops.avgpool3_stats_rows(self.praw.npix, cout)
+            ctx.stats(self, "pstats", self.prows * 2 * cout)
         self.fused_fwd, self._gstats = None, None      # set by an InputGradGroup that also runs the forward conv
         self.bn_bwd_grouped = False                    # True: the group runs this layer's BatchNorm backward
         self.bn_fwd_grouped = False                    # True: the group runs this layer's BatchNorm forward
@@ -552,7 +563,7 @@ class ConvBN:
             ctx.stats(self, "img_stats", c.N * 2 * cout, zeroed=True)
             self.img_save = torch.empty(c.N * 2 * cout, dtype=F32, device=ctx.device)
         self.sliced = (BN_FOLD and ctx.training and self.raw.npix * cout <= BN_FOLD_MAX_ELEMS and not defer_apply
-                       and not self.per_image)
+                       and not self.per_image and not self.post_pool)
         if self.sliced:        # every fold row exists: a job-table launch runs 64-pixel tiles, more than the layer's own
             self.stat_rows = ops.bn_fold_rows()
         ctx.stats(self, "stats", self.stat_rows * 2 * cout, zeroed=self.sliced)
@@ -597,6 +608,19 @@ class ConvBN:
             if not self.defer_apply:
                 ops.bn_apply_images(self.raw, self.out.v, self.img_save, st.p[self.bn + ".weight"],
                                     st.p[self.bn + ".bias"], relu=self.act, accumulate=self.accumulate)
+            return
+        if self.post_pool:       # conv (own launch, or a channel slice of the sibling group's) -> pool + statistics -> BN
+            if self.fused_fwd is None:
+                c.conv(self.raw)
+            ops.avgpool3_stats(self.raw, self.praw, self.pstats)
+            if ctx.training:
+                ops.bn_finalize(self.pstats, self.prows, c.cout, self.praw.npix, self.save,
+                                st.b[self.bn + ".running_mean"], st.b[self.bn + ".running_var"],
+                                st.b[self.bn + ".num_batches_tracked"])
+            else:
+                ops.bn_eval_stats(st.b[self.bn + ".running_mean"], st.b[self.bn + ".running_var"], c.cout, self.save)
+            ops.bn_apply(self.praw, self.out.v, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
+                         relu=self.act, accumulate=self.accumulate)
             return
         # A conv bias in front of a train-mode BatchNorm cancels in the normalised output: the conv runs without
         # it and running_mean, the one place it shows, gets momentum * bias afterwards.
@@ -779,7 +803,7 @@ class InputGradGroup:
         self.fwd = (ctx.st is not None and ctx.training and len(self.members) >= 2 and
                     not any(m.bias_key for m in self.members))
         self.images = self.fwd and ctx.per_image          # one statistics row per image
-        self.folded = self.fwd and not self.images and all(m.sliced for m in self.members)
+        self.folded = self.fwd and not self.images and all(m.sliced or m.post_pool for m in self.members)
         self.fwd_jobs = None
         if self.fwd:
             self.total = total
@@ -875,6 +899,7 @@ FWD_BN_JOBS = not os.environ.get("RIED_NO_FWD_BN_JOBS")
 BN_BWD_FOLD = not os.environ.get("RIED_NO_BN_BWD_FOLD")
 LEVEL_JOBS = not os.environ.get("RIED_NO_LEVEL_JOBS")
 POOL_FOLD = not os.environ.get("RIED_NO_POOL_FOLD")
+POOL_AFTER = not os.environ.get("RIED_NO_POOL_AFTER")      # forward-only plans: branch_pool as conv -> pool (A/B switch)
 # BatchNorm backward of small layers as one launch (partial sums, grid barrier, apply) instead of two.  Off: measured
 # 7.81 against 7.79 ms per step - the barrier's atomic round trips cost what the launch boundary they replace costs
 # (43 launches fewer per step; RIED_BN_BWD_ONE=1 turns it on).
@@ -1268,6 +1293,13 @@ def _pool_branch(ctx, seq, prefix, xin: Slot, out_slice: Slot, cin, cout):
     pool launches they replace (measured 7.89 -> 8.07 ms per step; RIED_POOL_FOLD_TRAIN=1 turns it on, the parity
     tests pass either way)."""
     N, H, W, _ = xin.shape
+    if POOL_AFTER and not ctx.grads and ctx.st is not None and not ctx.per_image:
+        # forward-only plans: the 1x1 convolution first (in the block's sibling group when there is one), the pool on
+        # its cout channels.  32 slices of 512 x 512: the five pool branches took 0.97 ms of kernel time as folded 3x3
+        # convolutions (one of them the longest branch of its block); see ConvBN(post_pool=True).
+        seq.add(ConvBN(ctx, prefix + ".branch_pool", cin, cout, 1, 1, 0, xin, out_slice, accumulate=True,
+                       post_pool=True))
+        return
     if POOL_FOLD and cin % 64 == 0 and (not ctx.grads or os.environ.get("RIED_POOL_FOLD_TRAIN")):
         seq.add(ConvBN(ctx, prefix + ".branch_pool", cin, cout, 3, 1, 1, xin, out_slice, accumulate=True,
                        pool_fold=True))

@@ -507,6 +507,15 @@ def pool_fwd(x: View, y: View, mode: int):
     lib.ried_pool_fwd(x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, mode, _stream())
 
 
+def avgpool3_stats_rows(npix: int, C: int) -> int:
+    return lib.ried_avgpool3_stats_rows(npix, C)
+
+
+def avgpool3_stats(x: View, y: View, stats: torch.Tensor):
+    """y = avg_pool2d(x, 3, 1, 1); stats[rows][2][C] = per-block column sums of y and y * y (for bn_finalize)."""
+    lib.ried_avgpool3_stats(x.ptr, x.ld, y.ptr, y.ld, x.N, x.H, x.W, x.C, _p(stats), _stream())
+
+
 def pool_bwd(x: Optional[View], dy: View, dx: View, mode: int, accumulate=True, relu_mask=False):
     lib.ried_pool_bwd(None if x is None else x.ptr, 0 if x is None else x.ld, dy.ptr, dy.ld, dx.ptr, dx.ld, dx.N,
                       dx.H, dx.W, dx.C, mode, int(accumulate), int(relu_mask), _stream())

@@ -775,6 +775,32 @@ def test_average_pool_on_large_maps(N, C, H, W):
     assert got[:, :8].abs().max() == 0 and got[:, 8 + C:].abs().max() == 0
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 16, 16, 24), (3, 96, 8, 8), (2, 64, 64, 32)])
+def test_average_pool_with_batchnorm_statistics(N, C, H, W):
+    """ried_avgpool3_stats (the pool of a branch_pool applied AFTER its 1x1 convolution): y = avg_pool2d(x, 3, 1, 1) as
+    F.avg_pool2d computes it, and the partial rows reduce to the column sums of y and y^2 (fp32, before rounding):
+    1e-3 relative.  Through ried_bn_finalize the rows give the mean and 1 / sqrt(var + eps) of the pooled tensor.
+    And the commutation the engine relies on: pool(conv1x1(x)) == conv1x1(pool(x)) for a bias-free convolution."""
+    x = r(N, C, H, W, seed=23)
+    y = F.avg_pool2d(x, 3, 1, 1)
+    xv, yv = to_view(x), ops.new_view(N, H, W, C)
+    rows = ops.avgpool3_stats_rows(N * H * W, C)
+    stats = torch.full((rows, 2, C), float("nan"), device=DEV)
+    ops.avgpool3_stats(xv, yv, stats)
+    close(from_view(yv), y, 4e-3, "y")
+    s1, s2 = stats[:, 0].sum(0).cpu(), stats[:, 1].sum(0).cpu()
+    npix = N * H * W
+    assert torch.allclose(s1 / npix, y.mean((0, 2, 3)), rtol=1e-3, atol=1e-4)
+    assert torch.allclose(s2 / npix, (y * y).mean((0, 2, 3)), rtol=1e-3, atol=1e-5)
+    save = torch.empty(2 * C, device=DEV)
+    ops.bn_finalize(stats, rows, C, npix, save)
+    var = y.var((0, 2, 3), unbiased=False)
+    assert torch.allclose(save[:C].cpu(), y.mean((0, 2, 3)), rtol=1e-3, atol=1e-4)
+    assert torch.allclose(save[C:].cpu(), 1.0 / torch.sqrt(var + 1e-5), rtol=2e-3)
+    w = r(8, C, 1, 1, seed=24)
+    assert torch.allclose(F.avg_pool2d(F.conv2d(x, w), 3, 1, 1), F.conv2d(F.avg_pool2d(x, 3, 1, 1), w), rtol=1e-4, atol=1e-5)
+
+
 def test_maxpool_ties_first_max():
     x = torch.zeros(1, 8, 4, 4)
     y = F.max_pool2d(x.clone().requires_grad_(True), 3, 2, 1)

@@ -461,7 +461,9 @@ def test_slice_inference_is_the_batch_one_loop():
     one = InferenceEngine(sd, 1, H, H)
     for i in range(B):
         p1, s1 = one.run(x[i:i + 1].to(DEV), y[i:i + 1].to(DEV))
-        act_close(pred[i:i + 1], p1.cpu(), f"slice {i} vs the batch-1 engine", mx=5e-3, mean=5e-4)
+        # (the batch-1 plan pools the pool branches' convolution OUTPUT, the per-slice plan their input: the same
+        # arithmetic up to where bf16 rounding falls)
+        act_close(pred[i:i + 1], p1.cpu(), f"slice {i} vs the batch-1 engine", mx=1e-2, mean=1.5e-3)
         m1 = one.measures(s1)[0]
         for a, b in zip(got[i][1], m1[1]):
             assert abs(a - b) <= 2e-3 * abs(b) + 1e-5, (i, got[i], m1)
@@ -492,7 +494,9 @@ def test_per_slice_statistics_inside_the_batched_kernels():
     worst = 0.0
     for i in range(B):
         p1, s1 = one.run(x[i:i + 1].to(DEV), y[i:i + 1].to(DEV))
-        act_close(pred[i:i + 1], p1.cpu(), f"slice {i} vs the batch-1 engine", mx=5e-3, mean=5e-4)
+        # (the batch-1 plan pools the pool branches' convolution OUTPUT, the per-slice plan their input: the same
+        # arithmetic up to where bf16 rounding falls)
+        act_close(pred[i:i + 1], p1.cpu(), f"slice {i} vs the batch-1 engine", mx=1e-2, mean=1.5e-3)
         worst = max(worst, (pred[i:i + 1] - p1.cpu()).abs().mean().item())
         m1 = one.measures(s1)[0]
         for a, b in zip(got[i][1], m1[1]):
