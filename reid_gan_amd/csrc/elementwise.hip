@@ -1453,7 +1453,7 @@ __global__ __launch_bounds__(EW_THREADS) void avgpool3_stats_kernel(const bf16_t
 // rows of the statistics buffer ([rows][2][C]) that ried_avgpool3_stats writes
 extern "C" int ried_avgpool3_stats_rows(long long npix, int C) {
   const int ppp = EW_THREADS / (C / 8);
-  long long rows = (npix + (long long)ppp * 8 - 1) / ((long long)ppp * 8);          // about eight passes per block
+  long long rows = (npix + (long long)ppp * 2 - 1) / ((long long)ppp * 2);          // two passes per block, at most 1024 rows
   return (int)(rows < 1 ? 1 : rows > 1024 ? 1024 : rows);
 }
 
