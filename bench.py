@@ -148,7 +148,7 @@ def _pmc_tables():
     and MFMA-busy fraction per kernel name; the newest round's files win."""
     root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     traffic, busy = None, {}
-    for r in ("r02", "r01"):
+    for r in ("r03", "r02", "r01"):
         f = os.path.join(root, f"{r}_pmc_conv_traffic.json")
         if traffic is None and os.path.exists(f):
             traffic = json.load(open(f))
