@@ -1333,6 +1333,155 @@ __global__ __launch_bounds__(512, NBB == 1 ? 4 : 2) void conv_halo_kernel(const 
 }
 
 // ---------------------------------------------------------------------------
+// 3x3, stride 2, pad 1 convolution FORWARD (src/rinet.py:21-24: the discriminator's strided layers; :56 conv2),
+// halo-tile form.  The general kernel fetches the input pixels once per tap and is bound by that L2 -> LDS traffic
+// (51 flop per byte at its 64 x 256 tile).  A stride-2 window needs (2 TS + 1)^2 input pixels for TS^2 outputs - 1089
+// for a 16 x 16 tile, 139 KB per 64-channel slab - so the tile is held in 32-channel HALF slabs (64 bytes per pixel,
+// 70 KB): a block owns 16 x 16 output pixels of one image and BM output channels, loads the 33 x 33 input tile of a
+// half slab once and runs its nine taps from it, one k-slice of 32 per tap; only the weights stream (four-stage ring
+// of BM x 32).  Per half slab 1089 * 64 + 9 * BM * 64 bytes for 2 * BM * 256 * 288 flops: 132 flop per byte at BM =
+// 128.  There is room for ONE tile buffer: the next half slab is fetched when every wave has read the current one
+// (one memory round trip per half slab; a layer with 64 input channels pays it once per block).
+//
+// LDS images have 64-byte rows.  Input tile: pixel (hy, hx) is row hy * 33 + (hx & 1) * 17 + (hx >> 1) - even and odd
+// columns apart, so that the sixteen pixels a fragment read takes (one output row: columns 2 ox + c) are sixteen
+// CONSECUTIVE rows; chunk q of row r sits in slot q ^ ((r >> 2) & 3), which puts the 16 lanes of a ds_read_b128
+// pass on 16 different bank slots (rows 64 bytes apart: four rows per 256-byte window, four slots each).  The same
+// swizzle for the weight rows.  All loads are LDS-DMA; padding and rows past Cout use out-of-range offsets (zeros).
+// Requires Cin % 32 == 0, Ho % 16 == 0, Wo % 16 == 0, H == 2 Ho, W == 2 Wo (host-checked).
+// ---------------------------------------------------------------------------
+template <int BM>
+__global__ __launch_bounds__(512, 2) void conv_halo_s2f_kernel(const GemmParams P) {
+  constexpr int TS = 16, BN = 256, WN = 4;
+  constexpr int TWI = 2 * TS + 1, HR = TWI * TWI;          // 33 x 33 input pixels
+  constexpr int NLB = (HR * 4 + 511) / 512;                // 9 DMA loads per lane per half slab
+  constexpr int BBUF = NLB * 512 * 16;                     // 72 KB
+  constexpr int ABUF = BM * 64, NSA = 4;                   // weight ring: four stages of BM rows x 32 channels
+  constexpr int TM = BM / 32, TN = 4;
+  static_assert(BM == 64 || BM == 128, "output-channel tile");
+  constexpr unsigned A_OOB = 0xFFFF0000u, B_OOB = 0xFFFFF000u;
+  __shared__ __attribute__((aligned(1024))) char smem[NSA * ABUF + BBUF];
+  char* const sA = smem;
+  char* const sB = smem + NSA * ABUF;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const GemmOperand& X = P.B;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A.p, 0, P.A_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B.p, 0, P.B_bytes, 0x00020000);
+  const int ntotal = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int nwg = ntotal, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tm = bid % P.tiles_m, tn = bid / P.tiles_m;
+  const int m0 = tm * BM;
+  const int tX = X.Wo / TS, tY = X.Ho / TS;
+  const int img0 = tn / (tX * tY), trem = tn % (tX * tY);
+  const int ty0 = (trem / tX) * TS, tx0 = (trem % tX) * TS;        // output tile origin
+  const int nhalf = P.K >> 5;
+
+  // weights: lane -> (row m, slot); the first BM * 4 lanes of the block carry a stage
+  const bool a_lane = tid < BM * 4;
+  unsigned aoff;
+  {
+    const int m = tid >> 2, q = (tid & 3) ^ ((m >> 2) & 3);
+    aoff = (a_lane && m0 + m < P.M) ? (unsigned)(m0 + m) * (unsigned)P.A.ld * 2u + (unsigned)q * 16u : A_OOB;
+  }
+  unsigned boff[NLB];
+#pragma unroll
+  for (int i = 0; i < NLB; ++i) {
+    const int ci = i * 512 + tid, row = ci >> 2, q = (ci & 3) ^ ((row >> 2) & 3);
+    const int hy = row / TWI, rem = row - hy * TWI;
+    const int hx = rem < TS + 1 ? 2 * rem : 2 * (rem - (TS + 1)) + 1;
+    const int iy = 2 * ty0 - 1 + hy, ix = 2 * tx0 - 1 + hx;
+    const bool ok = row < HR && (unsigned)iy < (unsigned)X.H && (unsigned)ix < (unsigned)X.W;
+    boff[i] = ok ? (unsigned)((img0 * X.H + iy) * X.W + ix) * (unsigned)X.ld * 2u + (unsigned)q * 16u : B_OOB;
+  }
+  char* const dA = sA + wave * 1024;
+  char* const dB = sB + wave * 1024;
+  // weights of global step sg = half * 9 + tap -> ring stage sg % 4; steps past the end fetch zeros nobody reads
+  auto issueA = [&](int sg) {
+    const int h = sg / 9, tap = sg - h * 9;
+    unsigned dead = h < nhalf ? 0u : A_OOB;
+    asm volatile("" : "+v"(dead));
+    const unsigned wk = (unsigned)(tap * P.K + h * 32) * 2u;
+    if (BM == 128 || wave < BM / 16) glds16(rsA, (aoff + wk) | dead, dA + (sg & (NSA - 1)) * ABUF);
+  };
+  auto issueB = [&](int h) {
+#pragma unroll
+    for (int part = 0; part < NLB; ++part) glds16(rsB, boff[part] + (unsigned)h * 64u, dB + part * 8192);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int kq = lane >> 4;                                  // this lane's 16-byte k chunk of the 32-channel slice
+  const int fa_off = (lane & 15) * 64 + ((kq ^ ((lane >> 2) & 3)) << 4);      // rows wm * (BM/2) + 16 i + lane % 16
+  int hr0[TN];                        // LDS row of this lane's output pixel (oy = 4 wn + j, ox = lane % 16) at tap (0, 0)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) hr0[j] = 2 * (wn * 4 + j) * TWI + (lane & 15);
+  bf16x8_t fa[TM], fb[TN];
+  auto load_frags = [&](int stage, int toff) {
+    const char* sa = sA + stage * ABUF + wm * (BM / 2) * 64 + fa_off;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(sa + i * 1024);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int hr = hr0[j] + toff;
+      fb[j] = *reinterpret_cast<const bf16x8_t*>(sB + hr * 64 + ((kq ^ ((hr >> 2) & 3)) << 4));
+    }
+  };
+
+  issueB(0);
+  issueA(0);
+  issueA(1);
+  issueA(2);
+  constexpr bool A_ALL = BM == 128;      // every wave issues weights (else only the first BM / 16 waves: their own counts)
+  for (int h = 0; h < nhalf; ++h) {
+    if (h > 0) {                         // every wave has read the tile: fetch the next half slab over it
+      __builtin_amdgcn_s_barrier();
+      issueB(h);
+    }
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int sg = h * 9 + tap;
+      // this step's weights were issued three steps ago; the two steps issued since may stay in flight.  The first
+      // step of a later half slab also waits for the tile, which was issued last.  (Waves that issue no weights
+      // have nothing but the tile in flight.)
+      if (tap == 0 && h > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (A_ALL || wave < BM / 16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      const int r = tap / 3, c = tap - r * 3;
+      load_frags(sg & (NSA - 1), r * TWI + (c & 1) * (TS + 1) + (c >> 1));
+      issueA(sg + 3);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  struct TileRowMap {
+    long long base; int W;
+    __device__ __forceinline__ bool operator()(int nl, long long& orow) const {
+      orow = base + (long long)(nl / TS) * W + (nl % TS);
+      return true;
+    }
+  };
+  const TileRowMap rm{((long long)img0 * X.Ho + ty0) * X.Wo + tx0, X.Wo};
+  gemm_epilogue_staged<BM, BN, WN, NSA * ABUF + BBUF>(P, acc, m0, rm, tn, ntotal / P.tiles_m, 0, smem);
+}
+
+// ---------------------------------------------------------------------------
 // Data gradient of a 3x3, stride 2, pad 1 convolution (= transposed convolution onto a 2H x 2W map), halo-tile
 // form.  The general kernel runs each of the four output phases (row parity, column parity) as its own short
 // GEMM - 1, 2, 2 and 4 taps - and fetches the input once per tap.  Here a block owns TS x TS input positions
@@ -1947,7 +2096,7 @@ static void default_epilogue(GemmEpilogue& E) {
 
 // job: instead of launching, write the problem as a record for ried_conv2d_jobs (general kernel, 64 x 64 tiles)
 // which: instead of launching, report the kernel the call would take: {kind, bm, bn or tile side, stages} with kind
-// 0 = conv_glds_kernel, 1 = conv_halo_kernel, 2 = conv_halo_s2t_kernel, 3 = conv_halo_d4_kernel
+// 0 = conv_glds_kernel, 1 = conv_halo_kernel, 2 = conv_halo_s2t_kernel, 3 = conv_halo_d4_kernel, 4 = conv_halo_s2f_kernel
 struct ConvJobOut { void* rec; int* nblocks; int* which; };
 // input transform of the general kernel (GemmParams::xf_*)
 struct ConvXf { const float* save; const float* gamma; const float* beta; int act; };
@@ -2055,6 +2204,29 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     else if (bm == 64 && Cin == 64) hipLaunchKernelGGL((conv_halo_kernel<64, 16, 1>), hgrid, dim3(512), 0, stream, P);
     else if (bm == 64) hipLaunchKernelGGL((conv_halo_kernel<64, 16>), hgrid, dim3(512), 0, stream, P);
     else hipLaunchKernelGGL((conv_halo_kernel<128, 16>), hgrid, dim3(512), 0, stream, P);
+    RIED_CHECK_LAUNCH("ried_conv2d");
+    return RIED_OK;
+  }
+  // 3x3 stride-2 forward on maps of whole 16x16 output tiles: the half-slab halo kernel.  OFF unless asked for
+  // (ried_conv2d_force_tile(0, 1, 0)): measured on the discriminator's layers at 256 images it is slower than the
+  // general kernel - 64 -> 128 channels at 64 x 64: 87.9 against 74.5 us, 128 -> 256 at 32 x 32: 60.6 against 53.9 -
+  // although it moves 2.6x fewer bytes from L2 to LDS: at 104 KB of LDS and 212 registers it runs one block per CU,
+  // so nothing hides a block's prologue, its half-slab refill and its two-pass epilogue (the general kernel's 80 KB
+  // blocks run two per CU).  A form with 8 x 16 output tiles and 256 threads (68 KB: two blocks per CU) is what
+  // would have to be measured next.
+  if (!xf && g_forced_tile[0] == 0 && P.E.staged && !transposed && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 &&
+      pw == 1 && H == 2 * Ho && W == 2 * Wo && Cin % 32 == 0 && Ho % 16 == 0 && Wo % 16 == 0 && Cout >= 64 && !img_stats &&
+      a_bytes < 0xFFFF0000ll - 16384 && b_bytes < 0xFFFFF000ll - 1024 && g_forced_tile[2] != 3 &&
+      g_forced_tile[1] == 1) {
+    const int bm = Cout >= 128 ? 128 : 64;
+    P.tiles_m = ceil_div(Cout, bm);
+    const int ntiles = nimg * (Ho / 16) * (Wo / 16);
+    // the caller sized the statistics buffer for the general kernel's rows (npix / t.bn): the spare ones are zeroed
+    if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = ntiles; }
+    const dim3 hgrid(P.tiles_m * ntiles);
+    if (which) { which[0] = 4; which[1] = bm; which[2] = 16; which[3] = 0; return RIED_OK; }
+    if (bm == 128) hipLaunchKernelGGL(conv_halo_s2f_kernel<128>, hgrid, dim3(512), 0, stream, P);
+    else hipLaunchKernelGGL(conv_halo_s2f_kernel<64>, hgrid, dim3(512), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
     return RIED_OK;
   }

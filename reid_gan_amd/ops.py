@@ -106,7 +106,7 @@ def conv2d_which(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, tran
                           int(stats_post), ctypes.addressof(which))
     kind, bm, bn, nst = list(which)
     return (f"conv_glds_kernel<{bm},{bn},{nst}>", f"conv_halo_kernel<{bm},{bn},{nst}>", f"conv_halo_s2t_kernel<{bn}>",
-            f"conv_halo_d4_kernel<{bm}>")[kind]
+            f"conv_halo_d4_kernel<{bm}>", f"conv_halo_s2f_kernel<{bm}>")[kind]
 
 
 def conv2d_tap_mse(x: View, w: torch.Tensor, bias: torch.Tensor, y: View, target: torch.Tensor, gout: View,

@@ -206,6 +206,51 @@ def test_conv2d_stride2_data_gradient_halo_kernel(cin, cout, N, H, W):
         close(a, b, 4e-3, what + " vs general kernel")
 
 
+@pytest.mark.parametrize("cin,cout,N,H,W", [(64, 128, 2, 64, 64), (128, 256, 1, 32, 64), (32, 64, 2, 32, 32),
+                                             (96, 192, 1, 32, 32), (64, 72, 3, 32, 32)])
+def test_conv2d_stride2_forward_halo_kernel(cin, cout, N, H, W):
+    """3x3 stride-2 pad-1 forward on maps of whole 16x16 OUTPUT tiles takes the half-slab halo kernel (Cin a multiple
+    of 32; 64 or 128 output channels per block, rows past Cout are zeros): against torch with bias + LeakyReLU (the
+    discriminator's layers), and with BatchNorm statistics (plain rows, folded rows, a channel slice of a wider
+    buffer) against the general kernel."""
+    x = r(N, cin, H, W, seed=80)
+    w = r(cout, cin, 3, 3, seed=81, scale=(cin * 9) ** -0.5)
+    b = r(cout, seed=82, scale=0.1)
+    raw = F.conv2d(x, w, None, 2, 1)
+    ref = F.leaky_relu(raw + b.view(1, -1, 1, 1), 0.2)
+    wp = pack(w)
+    xv = to_view(x)
+    Ho, Wo = H // 2, W // 2
+    rows = ops.conv2d_stat_rows(N, Ho, Wo, cin, cout, 3, 3, 2, 2, False)
+    out = {}
+    for name, force in (("halo", (0, 1, 0)), ("general", (-1, 0, 0))):   # (0, 1, 0): the kernel whatever the block count
+        lib.ried_conv2d_force_tile(*force)
+        try:
+            assert ops.conv2d_which(xv, wp, ops.new_view(N, Ho, Wo, cout), 3, 3, 2, 2, 1, 1).startswith(
+                "conv_halo_s2f_kernel" if name == "halo" else "conv_glds_kernel")
+            yv = ops.new_view(N, Ho, Wo, cout)
+            ops.conv2d(xv, wp, yv, 3, 3, 2, 2, 1, 1, bias=b.to(DEV), act=2)
+            rv = ops.new_view(N, Ho, Wo, cout)
+            stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
+            ops.conv2d(xv, wp, rv, 3, 3, 2, 2, 1, 1, stats=stats)
+            big = ops.new_view(N, Ho, Wo, cout + 16, zero=True)
+            fold = torch.zeros(ops.bn_fold_rows(), 2, cout, device=DEV)
+            ops.conv2d(xv, wp, big.slice(8, 8 + cout), 3, 3, 2, 2, 1, 1, stats=fold, stats_post=2)
+            out[name] = (from_view(yv), from_view(rv), stats.sum(0).cpu(), from_view(big), fold.sum(0).cpu())
+        finally:
+            lib.ried_conv2d_force_tile(0, 0, 0)
+    y, yr, st, yb, fo = out["halo"]
+    close(y, ref, what="bias + LeakyReLU")
+    close(yr, raw, what="raw")
+    close(st[0], raw.sum((0, 2, 3)), 3e-3, "sum")
+    close(st[1], (raw * raw).sum((0, 2, 3)), 3e-3, "sum of squares")
+    close(yb[:, 8:8 + cout], raw, what="slice")
+    assert yb[:, :8].abs().max() == 0 and yb[:, 8 + cout:].abs().max() == 0
+    close(fo[1], (raw * raw).sum((0, 2, 3)), 3e-3, "folded sum of squares")
+    for a, c, what in zip(out["halo"], out["general"], ("y", "raw", "stats", "slice", "folded stats")):
+        close(a, c, 4e-3, what + " vs general kernel")
+
+
 @pytest.mark.parametrize("cin,cout,N,H,W", [(192, 64, 2, 16, 16), (96, 32, 1, 32, 16), (64, 48, 3, 16, 32),
                                              (32, 128, 1, 16, 16), (384, 128, 1, 16, 16), (96, 24, 2, 16, 16)])
 def test_deconv_4x4_stride2_halo_kernel(cin, cout, N, H, W):
