@@ -1350,15 +1350,19 @@ __global__ __launch_bounds__(512, NBB == 1 ? 4 : 2) void conv_halo_kernel(const 
 // swizzle for the weight rows.  All loads are LDS-DMA; padding and rows past Cout use out-of-range offsets (zeros).
 // Requires Cin % 32 == 0, Ho % 16 == 0, Wo % 16 == 0, H == 2 Ho, W == 2 Wo (host-checked).
 // ---------------------------------------------------------------------------
-template <int BM>
-__global__ __launch_bounds__(512, 2) void conv_halo_s2f_kernel(const GemmParams P) {
-  constexpr int TS = 16, BN = 256, WN = 4;
-  constexpr int TWI = 2 * TS + 1, HR = TWI * TWI;          // 33 x 33 input pixels
-  constexpr int NLB = (HR * 4 + 511) / 512;                // 9 DMA loads per lane per half slab
-  constexpr int BBUF = NLB * 512 * 16;                     // 72 KB
+// TH output rows per tile: 16 (512 threads, 104 KB of LDS at BM = 128: one block per CU) or 8 (256 threads, 68 KB: two
+// blocks per CU, so that one block's prologue, refill and epilogue run under the other's main loop).
+template <int BM, int TH>
+__global__ __launch_bounds__(TH * 32, 2) void conv_halo_s2f_kernel(const GemmParams P) {
+  constexpr int TS = 16, BN = TH * TS, NT = 2 * BN, WN = NT / 128;
+  constexpr int TWX = 2 * TS + 1, TWY = 2 * TH + 1, HR = TWX * TWY;      // 33 x 33 or 33 x 17 input pixels
+  constexpr int NLB = (HR * 4 + NT - 1) / NT;              // DMA loads per lane per half slab
+  constexpr int BBUF = NLB * NT * 16;
   constexpr int ABUF = BM * 64, NSA = 4;                   // weight ring: four stages of BM rows x 32 channels
+  constexpr int NLA = (BM * 4 + NT - 1) / NT;              // DMA loads per lane per weight stage (lanes past BM * 4: none)
+  constexpr int AW = BM * 4 >= NT ? 2 * WN : BM / 16;      // waves that carry weights
   constexpr int TM = BM / 32, TN = 4;
-  static_assert(BM == 64 || BM == 128, "output-channel tile");
+  static_assert((BM == 64 || BM == 128) && (TH == 16 || TH == 8), "tile");
   constexpr unsigned A_OOB = 0xFFFF0000u, B_OOB = 0xFFFFF000u;
   __shared__ __attribute__((aligned(1024))) char smem[NSA * ABUF + BBUF];
   char* const sA = smem;
@@ -1366,7 +1370,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2f_kernel(const GemmParams 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WN, wn = wave % WN;
   const GemmOperand& X = P.B;
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)P.A.p, 0, P.A_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc((void*)P.B.p, 0, P.B_bytes, 0x00020000);
@@ -1378,23 +1382,22 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2f_kernel(const GemmParams 
   }
   const int tm = bid % P.tiles_m, tn = bid / P.tiles_m;
   const int m0 = tm * BM;
-  const int tX = X.Wo / TS, tY = X.Ho / TS;
+  const int tX = X.Wo / TS, tY = X.Ho / TH;
   const int img0 = tn / (tX * tY), trem = tn % (tX * tY);
-  const int ty0 = (trem / tX) * TS, tx0 = (trem % tX) * TS;        // output tile origin
+  const int ty0 = (trem / tX) * TH, tx0 = (trem % tX) * TS;        // output tile origin
   const int nhalf = P.K >> 5;
 
-  // weights: lane -> (row m, slot); the first BM * 4 lanes of the block carry a stage
-  const bool a_lane = tid < BM * 4;
-  unsigned aoff;
-  {
-    const int m = tid >> 2, q = (tid & 3) ^ ((m >> 2) & 3);
-    aoff = (a_lane && m0 + m < P.M) ? (unsigned)(m0 + m) * (unsigned)P.A.ld * 2u + (unsigned)q * 16u : A_OOB;
+  unsigned aoff[NLA];
+#pragma unroll
+  for (int i = 0; i < NLA; ++i) {
+    const int ci = i * NT + tid, m = ci >> 2, q = (ci & 3) ^ ((m >> 2) & 3);
+    aoff[i] = (ci < BM * 4 && m0 + m < P.M) ? (unsigned)(m0 + m) * (unsigned)P.A.ld * 2u + (unsigned)q * 16u : A_OOB;
   }
   unsigned boff[NLB];
 #pragma unroll
   for (int i = 0; i < NLB; ++i) {
-    const int ci = i * 512 + tid, row = ci >> 2, q = (ci & 3) ^ ((row >> 2) & 3);
-    const int hy = row / TWI, rem = row - hy * TWI;
+    const int ci = i * NT + tid, row = ci >> 2, q = (ci & 3) ^ ((row >> 2) & 3);
+    const int hy = row / TWX, rem = row - hy * TWX;
     const int hx = rem < TS + 1 ? 2 * rem : 2 * (rem - (TS + 1)) + 1;
     const int iy = 2 * ty0 - 1 + hy, ix = 2 * tx0 - 1 + hx;
     const bool ok = row < HR && (unsigned)iy < (unsigned)X.H && (unsigned)ix < (unsigned)X.W;
@@ -1408,11 +1411,14 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2f_kernel(const GemmParams 
     unsigned dead = h < nhalf ? 0u : A_OOB;
     asm volatile("" : "+v"(dead));
     const unsigned wk = (unsigned)(tap * P.K + h * 32) * 2u;
-    if (BM == 128 || wave < BM / 16) glds16(rsA, (aoff + wk) | dead, dA + (sg & (NSA - 1)) * ABUF);
+    if (wave < AW) {
+#pragma unroll
+      for (int i = 0; i < NLA; ++i) glds16(rsA, (aoff[i] + wk) | dead, dA + (sg & (NSA - 1)) * ABUF + i * (NT * 16));
+    }
   };
   auto issueB = [&](int h) {
 #pragma unroll
-    for (int part = 0; part < NLB; ++part) glds16(rsB, boff[part] + (unsigned)h * 64u, dB + part * 8192);
+    for (int part = 0; part < NLB; ++part) glds16(rsB, boff[part] + (unsigned)h * 64u, dB + part * (NT * 16));
   };
 
   f32x4 acc[TM][TN];
@@ -1425,7 +1431,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2f_kernel(const GemmParams 
   const int fa_off = (lane & 15) * 64 + ((kq ^ ((lane >> 2) & 3)) << 4);      // rows wm * (BM/2) + 16 i + lane % 16
   int hr0[TN];                        // LDS row of this lane's output pixel (oy = 4 wn + j, ox = lane % 16) at tap (0, 0)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) hr0[j] = 2 * (wn * 4 + j) * TWI + (lane & 15);
+  for (int j = 0; j < TN; ++j) hr0[j] = 2 * (wn * 4 + j) * TWX + (lane & 15);
   bf16x8_t fa[TM], fb[TN];
   auto load_frags = [&](int stage, int toff) {
     const char* sa = sA + stage * ABUF + wm * (BM / 2) * 64 + fa_off;
@@ -1442,7 +1448,6 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2f_kernel(const GemmParams 
   issueA(0);
   issueA(1);
   issueA(2);
-  constexpr bool A_ALL = BM == 128;      // every wave issues weights (else only the first BM / 16 waves: their own counts)
   for (int h = 0; h < nhalf; ++h) {
     if (h > 0) {                         // every wave has read the tile: fetch the next half slab over it
       __builtin_amdgcn_s_barrier();
@@ -1454,12 +1459,11 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2f_kernel(const GemmParams 
       // this step's weights were issued three steps ago; the two steps issued since may stay in flight.  The first
       // step of a later half slab also waits for the tile, which was issued last.  (Waves that issue no weights
       // have nothing but the tile in flight.)
-      if (tap == 0 && h > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      else if (A_ALL || wave < BM / 16) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if ((tap == 0 && h > 0) || wave >= AW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLA) : "memory");
       __builtin_amdgcn_s_barrier();
       const int r = tap / 3, c = tap - r * 3;
-      load_frags(sg & (NSA - 1), r * TWI + (c & 1) * (TS + 1) + (c >> 1));
+      load_frags(sg & (NSA - 1), r * TWX + (c & 1) * (TS + 1) + (c >> 1));
       issueA(sg + 3);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -2208,25 +2212,30 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     return RIED_OK;
   }
   // 3x3 stride-2 forward on maps of whole 16x16 output tiles: the half-slab halo kernel.  OFF unless asked for
-  // (ried_conv2d_force_tile(0, 1, 0)): measured on the discriminator's layers at 256 images it is slower than the
-  // general kernel - 64 -> 128 channels at 64 x 64: 87.9 against 74.5 us, 128 -> 256 at 32 x 32: 60.6 against 53.9 -
-  // although it moves 2.6x fewer bytes from L2 to LDS: at 104 KB of LDS and 212 registers it runs one block per CU,
-  // so nothing hides a block's prologue, its half-slab refill and its two-pass epilogue (the general kernel's 80 KB
-  // blocks run two per CU).  A form with 8 x 16 output tiles and 256 threads (68 KB: two blocks per CU) is what
-  // would have to be measured next.
+  // (ried_conv2d_force_tile(0, 1, 0): 16 x 16 output tiles, one block per CU; (0, 2, 0): 8 x 16 tiles, two per CU).
+  // Measured on the discriminator's layers at 256 images against the general kernel: 64 -> 128 channels at 64 x 64:
+  // 89.7 / 77.0 against 78.7 us; 128 -> 256 at 32 x 32: 61.1 / 53.9 against 51.6; 256 -> 512 at 16 x 16: equal.  It
+  // moves 1.7-2.6x fewer bytes from L2 to LDS and gains nothing: the first layer reads 134 MB and writes 67 MB - 50 us
+  // of HBM time beside 40 us of matrix work that the one- or two-block-per-CU schedules do not overlap - so L2 -> LDS
+  // traffic was not what bounds these layers.
   if (!xf && g_forced_tile[0] == 0 && P.E.staged && !transposed && kh == 3 && kw == 3 && sh == 2 && sw == 2 && ph == 1 &&
       pw == 1 && H == 2 * Ho && W == 2 * Wo && Cin % 32 == 0 && Ho % 16 == 0 && Wo % 16 == 0 && Cout >= 64 && !img_stats &&
       a_bytes < 0xFFFF0000ll - 16384 && b_bytes < 0xFFFFF000ll - 1024 && g_forced_tile[2] != 3 &&
-      g_forced_tile[1] == 1) {
-    const int bm = Cout >= 128 ? 128 : 64;
+      (g_forced_tile[1] == 1 || g_forced_tile[1] == 2)) {      // 1: 16 x 16 output tiles, 2: 8 x 16
+    const int bm = Cout >= 128 ? 128 : 64, th = g_forced_tile[1] == 1 ? 16 : 8;
     P.tiles_m = ceil_div(Cout, bm);
-    const int ntiles = nimg * (Ho / 16) * (Wo / 16);
+    const int ntiles = nimg * (Ho / th) * (Wo / 16);
     // the caller sized the statistics buffer for the general kernel's rows (npix / t.bn): the spare ones are zeroed
-    if (stats && !P.E.stats_fold) { P.E.stats_zero = 256 / t.bn; P.E.stats_rows = ntiles; }
+    if (stats && !P.E.stats_fold) {
+      RIED_CHECK_ARG(th * 16 >= t.bn, "ried_conv2d: statistics rows of the 8 x 16 tiles do not fit the caller's buffer");
+      P.E.stats_zero = th * 16 / t.bn; P.E.stats_rows = ntiles;
+    }
     const dim3 hgrid(P.tiles_m * ntiles);
-    if (which) { which[0] = 4; which[1] = bm; which[2] = 16; which[3] = 0; return RIED_OK; }
-    if (bm == 128) hipLaunchKernelGGL(conv_halo_s2f_kernel<128>, hgrid, dim3(512), 0, stream, P);
-    else hipLaunchKernelGGL(conv_halo_s2f_kernel<64>, hgrid, dim3(512), 0, stream, P);
+    if (which) { which[0] = 4; which[1] = bm; which[2] = th; which[3] = 0; return RIED_OK; }
+    if (bm == 128 && th == 16) hipLaunchKernelGGL((conv_halo_s2f_kernel<128, 16>), hgrid, dim3(512), 0, stream, P);
+    else if (bm == 128) hipLaunchKernelGGL((conv_halo_s2f_kernel<128, 8>), hgrid, dim3(256), 0, stream, P);
+    else if (th == 16) hipLaunchKernelGGL((conv_halo_s2f_kernel<64, 16>), hgrid, dim3(512), 0, stream, P);
+    else hipLaunchKernelGGL((conv_halo_s2f_kernel<64, 8>), hgrid, dim3(256), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
     return RIED_OK;
   }

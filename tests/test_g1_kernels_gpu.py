@@ -206,9 +206,10 @@ def test_conv2d_stride2_data_gradient_halo_kernel(cin, cout, N, H, W):
         close(a, b, 4e-3, what + " vs general kernel")
 
 
+@pytest.mark.parametrize("th", [16, 8])
 @pytest.mark.parametrize("cin,cout,N,H,W", [(64, 128, 2, 64, 64), (128, 256, 1, 32, 64), (32, 64, 2, 32, 32),
                                              (96, 192, 1, 32, 32), (64, 72, 3, 32, 32)])
-def test_conv2d_stride2_forward_halo_kernel(cin, cout, N, H, W):
+def test_conv2d_stride2_forward_halo_kernel(cin, cout, N, H, W, th):
     """3x3 stride-2 pad-1 forward on maps of whole 16x16 OUTPUT tiles takes the half-slab halo kernel (Cin a multiple
     of 32; 64 or 128 output channels per block, rows past Cout are zeros): against torch with bias + LeakyReLU (the
     discriminator's layers), and with BatchNorm statistics (plain rows, folded rows, a channel slice of a wider
@@ -223,7 +224,8 @@ def test_conv2d_stride2_forward_halo_kernel(cin, cout, N, H, W):
     Ho, Wo = H // 2, W // 2
     rows = ops.conv2d_stat_rows(N, Ho, Wo, cin, cout, 3, 3, 2, 2, False)
     out = {}
-    for name, force in (("halo", (0, 1, 0)), ("general", (-1, 0, 0))):   # (0, 1, 0): the kernel whatever the block count
+    # (0, 1, 0) / (0, 2, 0): the halo kernel with 16 x 16 / 8 x 16 output tiles (it is off by default)
+    for name, force in (("halo", (0, 1 if th == 16 else 2, 0)), ("general", (-1, 0, 0))):
         lib.ried_conv2d_force_tile(*force)
         try:
             assert ops.conv2d_which(xv, wp, ops.new_view(N, Ho, Wo, cout), 3, 3, 2, 2, 1, 1).startswith(
