@@ -389,6 +389,37 @@ def test_inference_at_the_benchmark_size_vs_oracle():
         for a, b in zip(got[i][1], res[i][1]):
             assert abs(a - b) <= 2e-2 * abs(b), (i, got[i][1], res[i][1])
 
+@pytest.mark.parametrize("lookahead", [False, True])
+def test_reseeded_discriminator_steps_like_a_fresh_one(lookahead):
+    """TrainStep.reseed_discriminator(snapshot) between two steps (what bench.py does every few steps to keep the
+    hinge gates of DLoss open): the step after it sees the discriminator of the snapshot - weights, spectral-norm
+    vectors, Adam state - so its D losses are those of a plan whose discriminator never trained, on the same
+    generator.  A look-ahead plan has redone what it had prepared with the old discriminator."""
+    B, H = 4, 64
+    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
+    xs = [tuple(t.to(DEV) for t in synth_batch(B, H, seed=s)) for s in (11, 12, 13)]
+    a = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=True, lookahead=lookahead)
+    snap = a.snapshot_discriminator()
+    for i in range(2):
+        a.step(xs[i][0], xs[i][1], **({"y_next": xs[i + 1][1]} if lookahead else {}))
+    trained = a.losses()
+    a.reseed_discriminator(snap)
+    assert torch.equal(a.ds.flat, snap["flat"]) and int(a.ds.adam_step.item()) == 0
+    a.step(xs[2][0], xs[2][1])
+    got = a.losses()
+    # reference: a fresh discriminator beside the SAME generator (a's generator weights before that third step)
+    b = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False)
+    for i in range(2):
+        b.step(xs[i][0], xs[i][1])
+    b.reseed_discriminator(snap)
+    b.step(xs[2][0], xs[2][1])
+    ref = b.losses()
+    for k in ("dloss1", "dloss2", "gen"):
+        assert abs(got[k] - ref[k]) <= 1e-2 * abs(ref[k]) + 1e-5, (k, got[k], ref[k])
+    assert abs(got["dloss1"] - trained["dloss1"]) > 0.05          # (the trained discriminator had moved on)
+    a.close()
+
+
 def test_segmented_graphs_equal_single_graph(monkeypatch):
     """With several ranks the step is captured as graph segments split at the collectives (and the side streams
     must rejoin before each split).  Here the collectives are stubbed out (identical replicas: the mean over ranks

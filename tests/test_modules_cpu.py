@@ -63,3 +63,16 @@ def test_vgg_state_loading_accepts_torchvision_keys():
     assert set(got) == set(sv) and torch.equal(got["28.weight"], sv["28.weight"])
     with pytest.raises(ValueError):
         loss.load_vgg16_state({"features.0.weight": sv["0.weight"]})
+
+
+def test_split_counts_of_the_weight_gradients():
+    """engine._splitk: the default rule reaches a target block count; the whole-rounds rule (launches of their own: the
+    discriminator's) takes the largest count whose blocks fit two per CU - 9, 18, 72 and 144 (tile, tap) blocks are the
+    discriminator's four strided layers at 64 x 64 - and both keep at least `minpix` pixels per split."""
+    from reid_gan_amd.engine import _splitk
+    kp = 256 * 32 * 32
+    assert [_splitk(b, kp, whole_rounds=True) for b in (9, 18, 72, 144)] == [56, 28, 7, 3]
+    assert all(b * _splitk(b, kp, whole_rounds=True) <= max(b, 512) for b in range(1, 600))
+    assert _splitk(9, kp) == 43 and _splitk(144, kp) == 3                 # default: ceil(384 / blocks)
+    assert _splitk(9, 2048, whole_rounds=True) == 3 and _splitk(9, 2048) == 3     # 768 pixels per split at least
+    assert _splitk(1000, kp, whole_rounds=True) == 1
