@@ -441,9 +441,13 @@ def main():
     ap.add_argument("--no-infer", action="store_true")
     args = ap.parse_args()
 
-    from reid_gan_amd import dp
+    from reid_gan_amd import dp, ops
     from reid_gan_amd.synth import synth_batch
     from reid_gan_amd.train_step import TrainStep
+    try:          # native frames on stderr if the process dies on a signal (diagnostics only: never fatal itself)
+        ops.install_crash_backtrace(None)
+    except Exception:          # noqa: BLE001
+        pass
     if os.environ.get("RIED_HANG_DUMP"):      # debugging aid: every thread's stack after that many seconds, then exit
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RIED_HANG_DUMP"]), exit=True)
