@@ -59,6 +59,14 @@ int ried_conv2d(const void* x, long long ldx, const void* w, void* y, long long 
                 int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
                 const float* bias, int act, float* stats, int accumulate, int out_f32, float* y2, long long ldy2,
                 const void* mask, long long ldmask, float mask_slope, int stats_post, ried_stream_t stream);
+/* ried_conv2d (bf16 output) with the activation mask given as sign bytes, as ried_conv_c1_fwd_signs writes them:
+ * signs[p][ldsigns bytes], bit q of byte c set where channel 8c + q of the forward output was positive.  The backward
+ * of LeakyReLU (src/rinet.py:139) needs no more, and the 64-channel activation of the discriminator's first layer
+ * (src/rinet.py:20) is the largest tensor of the step: 1 byte instead of 16 per 8-channel chunk. */
+int ried_conv2d_signs(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
+                      int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
+                      const float* bias, int act, float* stats, int accumulate, const unsigned char* signs,
+                      long long ldsigns, float mask_slope, int stats_post, ried_stream_t stream);
 /* BasicConv2d / BasicDeconv2d (src/rinet.py:183-205) up to the BatchNorm statistics: y = raw bf16 conv result,
  * stats = partial rows as in ried_conv2d, and the last block to finish reduces them into save = (mean,
  * 1/sqrt(var+eps)) [2][Cout] and updates running_mean / running_var / num_batches_tracked (torch train-mode
@@ -328,6 +336,11 @@ int ried_sum_f32(const float* in, long long n, long long stride, float scale, in
 int ried_conv_c1_fwd(const float* x, const float* w, const float* sigma, const float* bias, void* y, long long ldy,
                      int nimg, int H, int W, int Cout, int stride, float in_scale, float in_shift, int act,
                      float* stats, ried_stream_t stream); /* stats: NULL or [ried_conv_c1_stat_rows(..)][2][Cout] */
+/* The same, and signs[p][Cout/8] (8-byte aligned; one byte per 8-channel chunk, bit q = channel 8*chunk + q) says
+ * which of the stored values are positive (for ried_conv2d_signs). */
+int ried_conv_c1_fwd_signs(const float* x, const float* w, const float* sigma, const float* bias, void* y,
+                           long long ldy, int nimg, int H, int W, int Cout, int stride, float in_scale, float in_shift,
+                           int act, float* stats, unsigned char* signs, ried_stream_t stream);
 int ried_conv_c1_stat_rows(int nimg, int H, int W, int Cout, int stride);
 /* dw[Cout][9] += ; scratch: fp32 [ried_conv_c1_wgrad_scratch_floats(Cout)] */
 int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy, int nimg, int H, int W, int Cout, int stride,

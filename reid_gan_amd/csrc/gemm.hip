@@ -53,6 +53,7 @@ struct GemmEpilogue {
   const bf16_t* mask;      // optional: final value *= (mask[row][m] > 0 ? 1 : mask_slope)  (activation backward
   long long ld_mask;       // fused into the data gradient that produces the tensor); applied after accumulate
   float mask_slope;
+  int mask_bits;           // 1: mask is sign BYTES instead ([row][ld_mask bytes], bit q of byte c = channel 8c + q positive)
   int stats_post;          // stats = column sums of the final values (bias gradient) instead of the raw results
   int stats_fold;          // > 0: rows are added (float atomics) into row (tile mod stats_fold) of a zeroed buffer
   int stats_img_tiles;     // > 0: rows are added into row (pixel tile / stats_img_tiles) = the tile's image
@@ -380,7 +381,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
           v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
         }
       }
-      if (E.mask) {
+      if (E.mask && E.mask_bits) {
+        const unsigned b = reinterpret_cast<const unsigned char*>(E.mask)[orow * E.ld_mask + (m >> 3)] >> (m & 4);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] *= ((b >> q) & 1u) ? 1.f : E.mask_slope;
+      } else if (E.mask) {
         u32x2 mk = *reinterpret_cast<const u32x2*>(E.mask + orow * E.ld_mask + m);
         v[0] *= bflo(mk[0]) > 0.f ? 1.f : E.mask_slope; v[1] *= bfhi(mk[0]) > 0.f ? 1.f : E.mask_slope;
         v[2] *= bflo(mk[1]) > 0.f ? 1.f : E.mask_slope; v[3] *= bfhi(mk[1]) > 0.f ? 1.f : E.mask_slope;
@@ -562,7 +567,12 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 
         v[0] += bflo(o[0]); v[1] += bfhi(o[0]); v[2] += bflo(o[1]); v[3] += bfhi(o[1]);
         v[4] += bflo(o[2]); v[5] += bfhi(o[2]); v[6] += bflo(o[3]); v[7] += bfhi(o[3]);
       }
-      if (E.mask) {
+      if (E.mask && E.mask_bits) {
+        const unsigned b = reinterpret_cast<const unsigned char*>(E.mask)[orow * E.ld_mask + (m >> 3)];
+        const float sl = E.mask_slope;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] *= ((b >> q) & 1u) ? 1.f : sl;
+      } else if (E.mask) {
         const u32x4 mk = *reinterpret_cast<const u32x4*>(E.mask + orow * E.ld_mask + m);
         const float sl = E.mask_slope;
         v[0] *= bflo(mk[0]) > 0.f ? 1.f : sl; v[1] *= bfhi(mk[0]) > 0.f ? 1.f : sl;
@@ -2114,7 +2124,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                        float* y2, long long ldy2, const void* mask, long long ldmask, float mask_slope,
                        int stats_post, const BnFinalize* fin, hipStream_t stream, const float* sub = nullptr,
                        long long ld_sub = 0, void* gout = nullptr, long long ld_gout = 0, float gscale = 0.f,
-                       const ConvJobOut* job = nullptr, const ConvXf* xf = nullptr) {
+                       const ConvJobOut* job = nullptr, const ConvXf* xf = nullptr, int mask_bits = 0) {
   RIED_CHECK_ARG(x && w && y, "ried_conv2d: null pointer");
   RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
   RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
@@ -2155,7 +2165,9 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   P.E.accumulate = accumulate;
   RIED_CHECK_ARG(!y2 || (ldy2 % 4 == 0 && ldy2 >= Cout && ((uintptr_t)y2 % 16) == 0), "ried_conv2d: bad y2 view");
   P.E.out2 = y2; P.E.ldc2 = ldy2;
-  RIED_CHECK_ARG(!mask || (ldmask % 4 == 0 && ldmask >= Cout && ((uintptr_t)mask % 8) == 0), "ried_conv2d: bad mask view");
+  if (mask_bits) RIED_CHECK_ARG(mask && ldmask >= Cout / 8 && !job && !fin, "ried_conv2d_signs: bad sign-byte view");
+  else RIED_CHECK_ARG(!mask || (ldmask % 4 == 0 && ldmask >= Cout && ((uintptr_t)mask % 8) == 0), "ried_conv2d: bad mask view");
+  P.E.mask_bits = mask_bits;
   P.E.mask = (const bf16_t*)mask; P.E.ld_mask = ldmask; P.E.mask_slope = mask_slope; P.E.stats_post = stats_post == 1;
   P.E.stats_fold = stats_post == 2 ? ried_bn_fold_rows() : 0;
   const bool img_stats = stats_post == 3;      // one row per image; every kernel below sets its tiles per image
@@ -2165,7 +2177,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                  "ried_conv2d: bad perceptual-tap arguments");
   P.E.sub = sub; P.E.ld_sub = ld_sub; P.E.gout = (bf16_t*)gout; P.E.ld_gout = ld_gout; P.E.gscale = gscale;
   P.E.staged = !fin && !out_f32 && ldy % 8 == 0 && ((uintptr_t)y % 16) == 0 &&
-               (!mask || (ldmask % 8 == 0 && ((uintptr_t)mask % 16) == 0)) && (!y2 || ((uintptr_t)y2 % 16) == 0) &&
+               (!mask || mask_bits || (ldmask % 8 == 0 && ((uintptr_t)mask % 16) == 0)) && (!y2 || ((uintptr_t)y2 % 16) == 0) &&
                (!gout || (ld_gout % 8 == 0 && ((uintptr_t)gout % 16) == 0)) && g_forced_tile[2] != -1;
   long long a_bytes = (long long)Cout * kh * kw * Cin * 2;
   long long b_bytes = (((long long)nimg * H * W - 1) * ldx + Cin) * 2;
@@ -2328,6 +2340,18 @@ extern "C" int ried_conv2d(const void* x, long long ldx, const void* w, void* y,
                            int stats_post, hipStream_t stream) {
   return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, bias, act,
                      stats, accumulate, out_f32, y2, ldy2, mask, ldmask, mask_slope, stats_post, nullptr, stream);
+}
+
+// ried_conv2d with the activation mask given as sign bytes (ried_conv_c1_fwd_signs): mask[p][ldmask bytes], bit q of
+// byte c set where channel 8c + q of the forward output was positive.
+extern "C" int ried_conv2d_signs(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H,
+                                 int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
+                                 int transposed, const float* bias, int act, float* stats, int accumulate,
+                                 const unsigned char* signs, long long ldsigns, float mask_slope, int stats_post,
+                                 hipStream_t stream) {
+  return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, bias, act,
+                     stats, accumulate, 0, nullptr, 0, signs, ldsigns, mask_slope, stats_post, nullptr, stream, nullptr, 0,
+                     nullptr, 0, 0.f, nullptr, nullptr, 1);
 }
 
 // ried_conv2d whose input x is the RAW convolution output of a BasicConv2d layer (src/rinet.py:183-205): the kernel

@@ -52,7 +52,7 @@ template <int COUT>
 __global__ __launch_bounds__(C1_TILE) void conv_c1_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sigma,
     const float* __restrict__ bias, bf16_t* __restrict__ y, long long ldy, int nimg, int H, int W, int Ho, int Wo,
-    int stride, float in_scale, float in_shift, int act, float* __restrict__ stats) {
+    int stride, float in_scale, float in_shift, int act, float* __restrict__ stats, unsigned char* __restrict__ signs) {
   constexpr int ROWB = COUT * 2 + 16;                 // bytes per pixel in the LDS tile (16 of padding)
   constexpr int CC = COUT / 8;
   __shared__ __attribute__((aligned(16))) char tile[C1_TILE * ROWB];
@@ -63,6 +63,9 @@ __global__ __launch_bounds__(C1_TILE) void conv_c1_fwd_kernel(
   float xv[9];
   c1_taps(x, p0 + threadIdx.x, npix, H, W, Ho, Wo, stride, in_scale, in_shift, xv);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned sg[CC / 4];                                // one bit per channel: the stored value is positive
+#pragma unroll
+  for (int i = 0; i < CC / 4; ++i) sg[i] = 0u;
 #pragma unroll
   for (int cc = 0; cc < CC; ++cc) {
     // The weights are indexed by compile-time constants off a kernel argument: they arrive through the scalar
@@ -90,9 +93,15 @@ __global__ __launch_bounds__(C1_TILE) void conv_c1_fwd_kernel(
       if (act == 1) v = fmaxf(v, 0.f);
       else if (act == 2) v = v > 0.f ? v : 0.2f * v;
       acc[q] = v;
+      sg[cc / 4] |= (v > 0.f ? 1u : 0u) << ((cc & 3) * 8 + q);
     }
     *reinterpret_cast<u32x4*>(tile + threadIdx.x * ROWB + cc * 16) =
         u32x4{pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
+  }
+  if (signs && p0 + threadIdx.x < npix) {               // CC bytes per pixel, consecutive lanes consecutive pixels
+    unsigned* sp = reinterpret_cast<unsigned*>(signs + (p0 + threadIdx.x) * CC);
+    if constexpr (CC == 8) *reinterpret_cast<u32x2*>(sp) = u32x2{sg[0], sg[1]};
+    else sp[0] = sg[0];
   }
   __syncthreads();
 #pragma unroll
@@ -108,10 +117,11 @@ __global__ __launch_bounds__(C1_TILE) void conv_c1_fwd_kernel(
   }
 }
 
-extern "C" int ried_conv_c1_fwd(const float* x, const float* w, const float* sigma, const float* bias, void* y,
-                                long long ldy, int nimg, int H, int W, int Cout, int stride, float in_scale,
-                                float in_shift, int act, float* stats, hipStream_t stream) {
+static int conv_c1_fwd_impl(const float* x, const float* w, const float* sigma, const float* bias, void* y,
+                            long long ldy, int nimg, int H, int W, int Cout, int stride, float in_scale,
+                            float in_shift, int act, float* stats, unsigned char* signs, hipStream_t stream) {
   RIED_CHECK_ARG(x && w && y && nimg > 0 && H > 0 && W > 0, "ried_conv_c1_fwd: bad arguments");
+  RIED_CHECK_ARG(((uintptr_t)signs % 8) == 0, "ried_conv_c1_fwd_signs: the sign bytes must be 8-byte aligned");
   RIED_CHECK_ARG(stride == 1 || stride == 2, "ried_conv_c1_fwd: stride must be 1 or 2");
   RIED_CHECK_ARG(ldy % 8 == 0 && ldy >= Cout && ((uintptr_t)y % 16) == 0, "ried_conv_c1_fwd: output view");
   RIED_CHECK_ARG(Cout == 32 || Cout == 64, "ried_conv_c1_fwd: Cout must be 32 or 64 (got %d)", Cout);
@@ -121,12 +131,27 @@ extern "C" int ried_conv_c1_fwd(const float* x, const float* w, const float* sig
   int grid = ceil_div(npix, C1_TILE);
   if (Cout == 32)
     hipLaunchKernelGGL(conv_c1_fwd_kernel<32>, dim3(grid), dim3(C1_TILE), 0, stream, x, w, sigma, bias,
-                       (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats);
+                       (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats, signs);
   else
     hipLaunchKernelGGL(conv_c1_fwd_kernel<64>, dim3(grid), dim3(C1_TILE), 0, stream, x, w, sigma, bias,
-                       (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats);
+                       (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats, signs);
   RIED_CHECK_LAUNCH("ried_conv_c1_fwd");
   return RIED_OK;
+}
+extern "C" int ried_conv_c1_fwd(const float* x, const float* w, const float* sigma, const float* bias, void* y,
+                                long long ldy, int nimg, int H, int W, int Cout, int stride, float in_scale,
+                                float in_shift, int act, float* stats, hipStream_t stream) {
+  return conv_c1_fwd_impl(x, w, sigma, bias, y, ldy, nimg, H, W, Cout, stride, in_scale, in_shift, act, stats, nullptr,
+                          stream);
+}
+// The same, and signs[p][Cout/8] (one byte per 8-channel chunk, bit q = channel 8*chunk + q) says which of the stored
+// values are positive: all that the backward of the activation needs (ried_conv2d_signs), at 1/16 of the bytes.
+extern "C" int ried_conv_c1_fwd_signs(const float* x, const float* w, const float* sigma, const float* bias, void* y,
+                                      long long ldy, int nimg, int H, int W, int Cout, int stride, float in_scale,
+                                      float in_shift, int act, float* stats, unsigned char* signs, hipStream_t stream) {
+  RIED_CHECK_ARG(signs != nullptr, "ried_conv_c1_fwd_signs: null pointer");
+  return conv_c1_fwd_impl(x, w, sigma, bias, y, ldy, nimg, H, W, Cout, stride, in_scale, in_shift, act, stats, signs,
+                          stream);
 }
 
 // rows of the partial-statistics buffer ([rows][2][Cout]) that ried_conv_c1_fwd writes when stats is given

@@ -102,6 +102,9 @@ class Act:
         # partial sums) and from then on g holds the gradient w.r.t. the PRE-activation values.
         self.fuse_slope: Optional[float] = None
         self.fused: Optional["_Fused"] = None
+        # uint8 [N*H*W][C/8], one bit per value of v (positive or not), written by the producer of v: the layer that
+        # writes g reads these instead of v for the activation backward (1/16 of the bytes)
+        self.signs: Optional[torch.Tensor] = None
 
     def slice(self, c0, c1) -> "Act":
         return Act(self.v.slice(c0, c1), None if self.g is None else self.g.slice(c0, c1))
@@ -1262,6 +1265,9 @@ def _chain(ctx: Ctx, seq: Seq, prefix: str, specs, xin: Slot, out: Slot, deconv=
 # 5.74 ms with every consumer.  So: stride-2 consumers by default (RIED_XF_FUSE=0: none, =1: all).  An earlier
 # form that transformed the operand in place in LDS cost the consumers 40-45 us each (LDS bandwidth).  Results are
 # bit-identical to apply + convolution (same fp32 scale / shift, same rounding to bf16).
+# The discriminator's first layer also writes one sign bit per activation and the second layer's data gradient reads
+# those for the LeakyReLU backward instead of the 64-channel activation itself (RIED_SIGN_MASK=0: the activation).
+SIGN_MASK = os.environ.get("RIED_SIGN_MASK", "1") != "0"
 XF_FUSE_MODE = os.environ.get("RIED_XF_FUSE", "s2")
 XF_FUSE = XF_FUSE_MODE not in ("", "0")
 
@@ -1595,6 +1601,8 @@ class SNConv:
             if first:
                 ctx.need_f32(ops.conv_c1_wgrad_scratch_floats(cout))
             out.act.fuse_slope = 0.2          # whoever writes out.g may apply this layer's LeakyReLU backward
+            if first and SIGN_MASK and cout % 8 == 0 and (out.c0, out.c1, out.n0, out.n1) == (0, cout, 0, N):
+                out.act.signs = torch.empty(N * Ho * Wo, cout // 8, dtype=torch.uint8, device=dev)
             if not first and xin.act.fuse_slope is not None:
                 _, H, W, _ = xin.shape
                 xin.act.fused = _Fused(ctx, N, H, W, cout, cin, 3, stride, stride)
@@ -1610,8 +1618,12 @@ class SNConv:
         out = self.out.images(n0, n1).v
         if self.first:
             self.x_img = x_img
+            sg = self.out.act.signs
+            if sg is not None:
+                hw = out.H * out.W
+                sg = sg[n0 * hw:n1 * hw]
             ops.conv_c1_fwd(x_img[n0:n1], st.p[p + ".weight_orig"], out, self.stride, sigma=self.sigma,
-                            bias=st.p[p + ".bias"], act=2)
+                            bias=st.p[p + ".bias"], act=2, signs=sg)
         else:
             self.core.conv(out, x=self.core.xin.images(n0, n1).v, bias=st.p[p + ".bias"], act=2)
 
@@ -1643,7 +1655,14 @@ class SNConv:
         else:
             xin = self.core.xin.images(n0, n1)
             xf = self.core.xin.act.fused
-            if xf is not None:
+            sg = self.core.xin.act.signs
+            if xf is not None and sg is not None:
+                c, hw = self.core, xin.shape[1] * xin.shape[2]
+                assert (xin.c0, xin.c1) == (0, sg.shape[1] * 8)
+                ops.conv2d_signs(dpre, c.wpt, xin.g, c.kh, c.kw, c.sh, c.sw, c.ph, c.pw, sg[xin.n0 * hw:xin.n1 * hw],
+                                 transposed=True, mask_slope=c.xin.act.fuse_slope, stats=xf.stats if wgrad else None,
+                                 stats_post=True)
+            elif xf is not None:
                 self.core.dgrad(dpre, xin.g, accumulate=False, mask=xin.v, mask_slope=self.core.xin.act.fuse_slope,
                                 stats=xf.stats if wgrad else None, stats_post=True)
             else:

@@ -85,6 +85,15 @@ def conv2d(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed
                     _stream())
 
 
+def conv2d_signs(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, signs: torch.Tensor, transposed=False,
+                 bias=None, act=0, stats=None, accumulate=False, mask_slope=0.0, stats_post=False):
+    """conv2d with the activation mask as sign bytes: signs uint8 [y pixels][y.C // 8] (conv_c1_fwd(..., signs=))."""
+    assert signs.dtype == torch.uint8 and signs.is_contiguous() and signs.numel() == y.npix * (y.C // 8)
+    lib.ried_conv2d_signs(x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C, kh, kw, sh, sw, ph, pw,
+                          int(transposed), _p(bias), act, _p(stats), int(accumulate), _p(signs), y.C // 8, mask_slope,
+                          int(stats_post), _stream())
+
+
 def conv2d_xf(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, xf_save, xf_gamma, xf_beta, xf_act=1,
               transposed=False, bias=None, act=0, stats=None, accumulate=False, stats_post=False):
     """conv2d on act(batchnorm(x)) with x the raw convolution output of the producing layer (save = its mean /
@@ -578,8 +587,14 @@ def sum_f32(x: torch.Tensor, n: int, stride: int, scale: float, out: torch.Tenso
 
 # --------------------------------------------------------------------------- special layers
 def conv_c1_fwd(x: torch.Tensor, w, y: View, stride, sigma=None, bias=None, in_scale=1.0, in_shift=0.0, act=0,
-                stats=None):
+                stats=None, signs: Optional[torch.Tensor] = None):
+    """signs: optional uint8 [pixels of y][y.C // 8] that receives one bit per stored value (positive or not)."""
     n, h, wd = x.shape[0], x.shape[-2], x.shape[-1]
+    if signs is not None:
+        assert signs.dtype == torch.uint8 and signs.is_contiguous() and signs.numel() == y.npix * (y.C // 8)
+        lib.ried_conv_c1_fwd_signs(_p(x), _p(w), _p(sigma), _p(bias), y.ptr, y.ld, n, h, wd, y.C, stride, in_scale,
+                                   in_shift, act, _p(stats), _p(signs), _stream())
+        return
     lib.ried_conv_c1_fwd(_p(x), _p(w), _p(sigma), _p(bias), y.ptr, y.ld, n, h, wd, y.C, stride, in_scale, in_shift,
                          act, _p(stats), _stream())
 

@@ -469,6 +469,43 @@ def test_conv2d_fused_activation_backward_and_bias_sums(cin, cout, s, slope, acc
     close(bias.cpu(), ref.sum((0, 2, 3)), 2e-2, "bias gradient")
 
 
+def _sign_bytes(y_nchw: torch.Tensor) -> torch.Tensor:
+    """uint8 [pixels][C/8]: bit q of byte c set where channel 8c + q is positive."""
+    N, C, H, W = y_nchw.shape
+    bits = (y_nchw.permute(0, 2, 3, 1).reshape(-1, C // 8, 8) > 0).to(torch.int32)
+    return (bits << torch.arange(8, dtype=torch.int32)).sum(-1).to(torch.uint8)
+
+
+@pytest.mark.parametrize("cin,cout,s,slope,N,H", [(128, 64, 2, 0.2, 3, 16), (128, 64, 2, 0.2, 2, 8), (64, 72, 1, 0.0, 3, 8),
+                                                  (64, 32, 2, 0.2, 1, 16)])
+def test_conv2d_activation_backward_from_sign_bytes(cin, cout, s, slope, N, H):
+    """The same fused data gradient with the mask given as one bit per value: bit-identical to the bf16 mask (the
+    stride-2 halo kernel's staged epilogue at 16 x 16 maps, the general kernel's two epilogues otherwise)."""
+    g = r(N, cin, H, H, seed=45)
+    w = r(cin, cout, 3, 3, seed=46, scale=(cin * 9) ** -0.5)
+    Ho = H * s
+    yact = r(N, cout, Ho, Ho, seed=47)
+    rows = ops.conv2d_stat_rows(N, Ho, Ho, cin, cout, 3, 3, s, s, True)
+    outs = []
+    for bits in (False, True):
+        yv = ops.new_view(N, Ho, Ho, cout)
+        stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
+        if bits:
+            ops.conv2d_signs(to_view(g), pack(w.permute(1, 0, 2, 3)), yv, 3, 3, s, s, 1, 1,
+                             _sign_bytes(yact).to(DEV).contiguous(), transposed=True, mask_slope=slope, stats=stats,
+                             stats_post=True)
+        else:
+            ops.conv2d(to_view(g), pack(w.permute(1, 0, 2, 3)), yv, 3, 3, s, s, 1, 1, transposed=True,
+                       mask=to_view(yact), mask_slope=slope, stats=stats, stats_post=True)
+        bias = torch.zeros(cout, device=DEV)
+        ops.stat_rows_sum(stats, rows, cout, bias)
+        outs.append((from_view(yv), bias.cpu()))
+    ref = F.conv_transpose2d(g, w, None, s, 1, output_padding=s - 1) * torch.where(yact > 0, 1.0, slope)
+    close(outs[1][0], ref, what="masked dgrad from sign bytes")
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1])
+
+
 def test_maxpool_bwd_overwrite_and_relu_mask():
     x = r(2, 16, 8, 8, seed=51)
     xr = x.clone().requires_grad_(True)
@@ -921,6 +958,13 @@ def test_conv_c1(cout, stride):
     ops.conv_c1_fwd(x.to(DEV), w.detach().to(DEV), yv, stride, sigma=sigma.to(DEV), bias=b.to(DEV),
                     in_scale=1 / 4096.0, in_shift=0.25, act=2, stats=stats)
     close(from_view(yv), y.detach(), what="y")
+    # the same call also writing one sign bit per stored value
+    yv2 = ops.new_view(N, Ho, Ho, cout)
+    signs = torch.full((N * Ho * Ho, cout // 8), 0xA5, dtype=torch.uint8, device=DEV)
+    ops.conv_c1_fwd(x.to(DEV), w.detach().to(DEV), yv2, stride, sigma=sigma.to(DEV), bias=b.to(DEV),
+                    in_scale=1 / 4096.0, in_shift=0.25, act=2, signs=signs)
+    assert torch.equal(from_view(yv2), from_view(yv))
+    assert torch.equal(signs.cpu(), _sign_bytes(from_view(yv)))
     raw = F.conv2d(xa, w.detach() / sigma, None, stride, 1)
     close(stats.sum(0)[0].cpu(), raw.sum((0, 2, 3)), 1e-3, "sum")
     dy = r(*y.shape, seed=26)
