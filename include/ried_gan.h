@@ -67,6 +67,22 @@ int ried_conv2d_signs(const void* x, long long ldx, const void* w, void* y, long
                       int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
                       const float* bias, int act, float* stats, int accumulate, const unsigned char* signs,
                       long long ldsigns, float mask_slope, int stats_post, ried_stream_t stream);
+/* Backward of the discriminator's second layer into its first (autograd of src/rinet.py:20-21) when only parameter
+ * gradients are wanted (the discriminator's own updates, src/train.py:156-165): the data gradient of the 3x3 stride-2
+ * convolution (dy: view [nimg][H][W] with Cin channels; wt: its packed transposed weights [64][3][3][Cin]) is masked
+ * with the first layer's LeakyReLU (mask: that layer's output as a bf16 view with ldmask elements per pixel, or its
+ * sign bytes with ldmask bytes per pixel when mask_bits = 1), its column sums go to stats (rows as ried_conv2d with
+ * stats_post = 1: the first layer's bias gradient), and its product with the nine taps of the first layer's fp32 input
+ * ximg [nimg][2H][2W] (used as ximg * in_scale + in_shift, zero padded) is ADDED to dw [64][9], the first layer's
+ * weight gradient.  The masked gradient itself - the largest tensor of the step - is never written.  H, W multiples
+ * of 16; scratch: fp32 [ried_conv2d_s2_dgrad_c1fold_scratch_floats(nimg, H, W)]. */
+int ried_conv2d_s2_dgrad_c1fold(const void* dy, long long lddy, const void* wt, int nimg, int H, int W, int Cin,
+                                const void* mask, long long ldmask, int mask_bits, float mask_slope, float* stats,
+                                const float* ximg, float in_scale, float in_shift, float* dw, float* scratch,
+                                ried_stream_t stream);
+long long ried_conv2d_s2_dgrad_c1fold_scratch_floats(int nimg, int H, int W);
+/* out[c] += sum over r < nrows of part[r][c], c < width: partial rows that blocks wrote without atomics */
+int ried_rows_add(const float* part, int nrows, int width, float* out, ried_stream_t stream);
 /* BasicConv2d / BasicDeconv2d (src/rinet.py:183-205) up to the BatchNorm statistics: y = raw bf16 conv result,
  * stats = partial rows as in ried_conv2d, and the last block to finish reduces them into save = (mean,
  * 1/sqrt(var+eps)) [2][Cout] and updates running_mean / running_var / num_batches_tracked (torch train-mode

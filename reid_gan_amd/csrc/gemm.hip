@@ -66,6 +66,12 @@ struct GemmEpilogue {
   long long ld_gout;
   float gscale;
   int phase_mode, Wo_full, HoWo_full, Hq, Wq, sh, sw;   // logical row -> physical pixel
+  // conv_halo_s2t_kernel<16, true> only: the result (64 channels: the gradient of the first discriminator layer's
+  // pre-activation) is not stored; its product with the nine taps of the fp32 image that layer reads - that layer's
+  // weight gradient - leaves the block as one row [64][9] of fold_rows
+  const float* fold_x;     // fp32 [nimg][2H][2W], used as fold_x * fold_scale + fold_shift, zero padded
+  float fold_scale, fold_shift;
+  float* fold_rows;        // [pixel tiles][64 * 9]
   int staged;              // bf16 output with every view 16-byte aligned: the convolution kernels may take the
                            // LDS-staged epilogue (full-line loads and stores)
 };
@@ -478,10 +484,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& P, f32x4 (&acc)[
 // CARRY (kernels that run several epilogues per block - the output phases of a tile; whole-tile staging only):
 // 1 = the thread's statistics sums are added into carry[16] and nothing is reduced or written, 2 = carry is
 // added in before the block's one reduction.  A thread's chunk column is the same in every call.
-template <int BM, int BN, int WN, int SMEM, class RowMap, int CARRY = 0>
+// FOLD: the final bf16 chunks go to the LDS tile dt ([pixel row of the tile][FOLD_DT_PITCH bytes]) instead of the
+// output tensor (rows outside the problem as zeros).
+constexpr int FOLD_DT_PITCH = 144, FOLD_XT_PITCH = 80;
+template <int BM, int BN, int WN, int SMEM, class RowMap, int CARRY = 0, bool FOLD = false>
 __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 (&acc)[BM / 32][BN / (16 * WN)],
                                                      int m0, const RowMap& rowmap, int tn, int ntiles_n, int by,
-                                                     void* smem, float* carry = nullptr) {
+                                                     void* smem, float* carry = nullptr, char* dt = nullptr) {
   constexpr int NT = 128 * WN, NW = 2 * WN, TM = BM / 32, TN = BN / (16 * WN);
   constexpr int HALVES = (BN * (BM + 4) * 4 + NW * 2 * BM * 4 <= SMEM) ? 1 : 2;
   static_assert(BN * (BM / HALVES + 4) * 4 + NW * 2 * (BM / HALVES) * 4 <= SMEM, "staging area");
@@ -536,7 +545,10 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 
         for (int q = 0; q < 8; ++q) { s0[q] += v[q]; s1[q] += v[q] * v[q]; }
       }
       long long orow;
-      if (!(rowmap(n, orow) && mok)) continue;
+      if (!(rowmap(n, orow) && mok)) {
+        if constexpr (FOLD) *reinterpret_cast<u32x4*>(dt + n * FOLD_DT_PITCH + c * 16) = u32x4{0, 0, 0, 0};
+        continue;
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] += bias8[q];
       if (E.act == 1) {
@@ -584,8 +596,9 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 
 #pragma unroll
         for (int q = 0; q < 8; ++q) { s0[q] += v[q]; s1[q] += v[q] * v[q]; }
       }
-      *reinterpret_cast<u32x4*>(op) =
-          u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+      const u32x4 packed = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+      if constexpr (FOLD) *reinterpret_cast<u32x4*>(dt + n * FOLD_DT_PITCH + c * 16) = packed;
+      else *reinterpret_cast<u32x4*>(op) = packed;
     }
     if (CARRY != 0 && E.stats) {
 #pragma unroll
@@ -1513,7 +1526,13 @@ struct S2tStep { int phase, wtap, shift_i, shift_j; };
 __device__ constexpr S2tStep S2T_STEPS[9] = {{0, 4, 0, 0}, {1, 5, 0, 0}, {2, 7, 0, 0}, {3, 8, 0, 0}, {1, 3, 0, 1},
                                              {3, 6, 0, 1}, {2, 1, 1, 0}, {3, 2, 1, 0}, {3, 0, 1, 1}};
 
-template <int TS>
+// FOLD (TS = 16, 64 output channels = the discriminator's first activation, src/rinet.py:20): the masked gradient is
+// not stored.  Each phase's 256 x 64 tile goes to LDS in bf16 (the rounding the stored tensor would have had) and is
+// multiplied on the matrix cores by the nine taps of the fp32 image under the same pixels - a [256][9] table built
+// from a 34 x 34 patch of the image that the block fetched before its main loop, split into bf16 high and low parts
+// so that the image keeps 16 bits of mantissa.  The block's [64][9] sums are one row of E.fold_rows: the first layer's
+// weight gradient without the 134 MB round trip of its output gradient and without a launch of its own.
+template <int TS, bool FOLD = false>
 __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams P) {
   constexpr int BM = 64, BN = 256, WN = 4;
   constexpr int IMG = BN / (TS * TS);
@@ -1525,7 +1544,15 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams 
   constexpr int ABUF = BM * 128;
   constexpr int TM = BM / 32, TN = 4;
   constexpr unsigned A_OOB = 0xFFFF0000u, B_OOB = 0xFFFFF000u;
-  __shared__ __attribute__((aligned(1024))) char smem[3 * ABUF + 2 * BBUF];
+  static_assert(!FOLD || TS == 16, "the fold needs one image per block");
+  constexpr int PIPE = 3 * ABUF + 2 * BBUF;
+  // FOLD: [staging tile + wave totals | gradient tile | tap table | image patch]; the patch lies behind the pipeline
+  constexpr int STG = BN * (BM + 4) * 4 + 8 * 2 * BM * 4;
+  constexpr int DT_OFF = STG, XT_OFF = DT_OFF + BN * FOLD_DT_PITCH, PATCH_OFF = XT_OFF + BN * FOLD_XT_PITCH;
+  constexpr int PW = 2 * TS + 2;                                      // patch side
+  static_assert(!FOLD || PATCH_OFF >= PIPE, "the patch must survive the main loop");
+  constexpr int SMEM = FOLD ? PATCH_OFF + PW * PW * 4 : PIPE;
+  __shared__ __attribute__((aligned(1024))) char smem[SMEM];
   char* const sA = smem;
   char* const sB = smem + 3 * ABUF;
 
@@ -1579,6 +1606,23 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams 
     asm volatile("" : "+v"(dead));
     glds16(rsB, (boff[part] + (unsigned)slab * 128u) | dead, dB + (slab & 1) * BBUF + part * 8192);
   };
+
+  // FOLD: the image patch under the tile's 32 x 32 output pixels and one pixel around them, held in registers
+  // across the main loop (the loads return under it) and written to LDS before the epilogues
+  constexpr int NPV = FOLD ? (PW * PW + 511) / 512 : 1;
+  float pv[NPV];
+  if constexpr (FOLD) {
+    const int IH = 2 * X.H, IW = 2 * X.W;
+    const float* img = P.E.fold_x + (long long)img0 * IH * IW;
+#pragma unroll
+    for (int i = 0; i < NPV; ++i) {
+      const int e = i * 512 + tid, py = e / PW, px = e - py * PW;
+      const int iy = 2 * ty0 - 1 + py, ix = 2 * tx0 - 1 + px;
+      const bool ok = e < PW * PW && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+      const float v = img[ok ? iy * IW + ix : 0];
+      pv[i] = ok ? v * P.E.fold_scale + P.E.fold_shift : 0.f;
+    }
+  }
 
   f32x4 acc[4][TM][TN];
 #pragma unroll
@@ -1658,17 +1702,95 @@ __global__ __launch_bounds__(512, 2) void conv_halo_s2t_kernel(const GemmParams 
   float carry[16];
 #pragma unroll
   for (int q = 0; q < 16; ++q) carry[q] = 0.f;
+  f32x4 facc[4];              // FOLD: [tap 16][channel 16 j + ..] partial products of this wave's 32 pixels per phase
+  float* const patch = reinterpret_cast<float*>(smem + (FOLD ? PATCH_OFF : 0));
+  if constexpr (FOLD) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) facc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NPV; ++i)
+      if (i * 512 + tid < PW * PW) patch[i * 512 + tid] = pv[i];
+    __syncthreads();
+  }
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     const PhaseRowMap rm{(long long)img0 * HWo + (long long)(2 * ty0 + (p >> 1)) * Wo + 2 * tx0 + (p & 1), Wo, HWo,
                          X.nimg - img0};
+    if constexpr (FOLD) {
+      // tap table of the phase: row n = pixel n of the tile, 16 bf16 high parts then 16 low parts (taps 0..8 used);
+      // waves 0-3 write the high halves, waves 4-7 the low halves
+      const int n = tid & 255, py = n >> 4, px = n & 15, half = tid >> 8;
+      const float* pp = patch + (2 * py + (p >> 1)) * PW + 2 * px + (p & 1);
+      unsigned short t16[16];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int z = 0; z < 3; ++z) {
+          const float xv = pp[r * PW + z];
+          const unsigned hi = pack2bf(xv, 0.f) & 0xFFFFu;
+          const float rest = xv - __uint_as_float(hi << 16);
+          t16[r * 3 + z] = half ? (unsigned short)(pack2bf(rest, 0.f) & 0xFFFFu) : (unsigned short)hi;
+        }
+#pragma unroll
+      for (int t = 9; t < 16; ++t) t16[t] = 0;
+      u32x4 w0, w1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        w0[e] = (unsigned)t16[2 * e] | ((unsigned)t16[2 * e + 1] << 16);
+        w1[e] = (unsigned)t16[8 + 2 * e] | ((unsigned)t16[9 + 2 * e] << 16);
+      }
+      char* xr = smem + XT_OFF + n * FOLD_XT_PITCH + half * 32;
+      *reinterpret_cast<u32x4*>(xr) = w0;
+      *reinterpret_cast<u32x4*>(xr + 16) = w1;
+    }
     if (p < 3)
-      gemm_epilogue_staged<BM, BN, WN, 3 * ABUF + 2 * BBUF, PhaseRowMap, 1>(P, acc[p], m0, rm, tn,
-                                                                            ntotal / P.tiles_m, 0, smem, carry);
+      gemm_epilogue_staged<BM, BN, WN, PIPE, PhaseRowMap, 1, FOLD>(P, acc[p], m0, rm, tn, ntotal / P.tiles_m, 0, smem,
+                                                                  carry, smem + DT_OFF);
     else
-      gemm_epilogue_staged<BM, BN, WN, 3 * ABUF + 2 * BBUF, PhaseRowMap, 2>(P, acc[p], m0, rm, tn,
-                                                                            ntotal / P.tiles_m, 0, smem, carry);
+      gemm_epilogue_staged<BM, BN, WN, PIPE, PhaseRowMap, 2, FOLD>(P, acc[p], m0, rm, tn, ntotal / P.tiles_m, 0, smem,
+                                                                  carry, smem + DT_OFF);
     __syncthreads();          // the LDS staging area is reused by the next phase
+    if constexpr (FOLD) {
+      // wave w: pixels [32 w, 32 w + 32) of the phase; both tiles are [pixel][row] images read with the transposing load
+      typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+      const int g = lane >> 4, q = (lane & 15) >> 2, pq = lane & 3;
+      const int k = wave * 32 + 8 * g + q;
+      auto tr_frag = [&](const char* base, int pitch, int row0) {
+        const char* a0 = base + k * pitch + (row0 + 4 * pq) * 2;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a0 + 4 * pitch));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return __builtin_bit_cast(bf16x8_t, r);
+      };
+      const bf16x8_t xh = tr_frag(smem + XT_OFF, FOLD_XT_PITCH, 0), xl = tr_frag(smem + XT_OFF, FOLD_XT_PITCH, 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bf16x8_t d = tr_frag(smem + DT_OFF, FOLD_DT_PITCH, 16 * j);
+        facc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh, d, facc[j], 0, 0, 0);
+        facc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl, d, facc[j], 0, 0, 0);
+      }
+      __syncthreads();        // the tables are rewritten by the next phase
+    }
+  }
+  if constexpr (FOLD) {
+    // the eight waves' sums through LDS (the staging tile is free), then one row [64][9] per block
+    float* red = reinterpret_cast<float*>(smem);           // [wave][tap 16][channel 64]
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        red[wave * 1024 + ((lane >> 4) * 4 + e) * 64 + j * 16 + (lane & 15)] = facc[j][e];
+    __syncthreads();
+    float* row = P.E.fold_rows + (long long)tn * (BM * 9);
+    for (int o = tid; o < BM * 9; o += 512) {
+      const int co = o / 9, tap = o - co * 9;
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[w * 1024 + tap * 64 + co];
+      row[o] = t;
+    }
   }
 }
 
@@ -2111,9 +2233,12 @@ static void default_epilogue(GemmEpilogue& E) {
 // job: instead of launching, write the problem as a record for ried_conv2d_jobs (general kernel, 64 x 64 tiles)
 // which: instead of launching, report the kernel the call would take: {kind, bm, bn or tile side, stages} with kind
 // 0 = conv_glds_kernel, 1 = conv_halo_kernel, 2 = conv_halo_s2t_kernel, 3 = conv_halo_d4_kernel, 4 = conv_halo_s2f_kernel
+extern "C" int ried_rows_add(const float* part, int nrows, int width, float* out, hipStream_t stream);
 struct ConvJobOut { void* rec; int* nblocks; int* which; };
 // input transform of the general kernel (GemmParams::xf_*)
 struct ConvXf { const float* save; const float* gamma; const float* beta; int act; };
+// first-layer weight gradient folded into the stride-2 data gradient (GemmEpilogue::fold_*)
+struct ConvFold { const float* x; float scale, shift; float* rows; };
 
 // Conv2d forward (transposed = 0) or ConvTranspose2d forward / strided-conv data gradient
 // (transposed = 1).  x: NHWC bf16 [nimg][H][W][ldx], channels 0..Cin-1 used.
@@ -2124,8 +2249,9 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                        float* y2, long long ldy2, const void* mask, long long ldmask, float mask_slope,
                        int stats_post, const BnFinalize* fin, hipStream_t stream, const float* sub = nullptr,
                        long long ld_sub = 0, void* gout = nullptr, long long ld_gout = 0, float gscale = 0.f,
-                       const ConvJobOut* job = nullptr, const ConvXf* xf = nullptr, int mask_bits = 0) {
-  RIED_CHECK_ARG(x && w && y, "ried_conv2d: null pointer");
+                       const ConvJobOut* job = nullptr, const ConvXf* xf = nullptr, int mask_bits = 0,
+                       const ConvFold* fold = nullptr) {
+  RIED_CHECK_ARG(x && w && (y || fold), "ried_conv2d: null pointer");
   RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
   RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
                  "ried_conv2d: channels/strides must be multiples of 8 (Cin=%d Cout=%d ldx=%lld ldy=%lld)", Cin, Cout,
@@ -2262,10 +2388,18 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     else if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * 256 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
     const dim3 hgrid(P.tiles_m * ntiles);
     if (which) { which[0] = 2; which[1] = 64; which[2] = 16; which[3] = 0; return RIED_OK; }
-    hipLaunchKernelGGL(conv_halo_s2t_kernel<16>, hgrid, dim3(512), 0, stream, P);
+    if (fold) {
+      RIED_CHECK_ARG(Cout == 64 && fold->x && fold->rows && !accumulate && !bias && !act && !y2 && !sub && !img_stats,
+                     "ried_conv2d_s2_dgrad_c1fold: 64 output channels, no accumulate / bias / activation / taps");
+      P.E.fold_x = fold->x; P.E.fold_scale = fold->scale; P.E.fold_shift = fold->shift; P.E.fold_rows = fold->rows;
+      hipLaunchKernelGGL((conv_halo_s2t_kernel<16, true>), hgrid, dim3(512), 0, stream, P);
+    } else {
+      hipLaunchKernelGGL(conv_halo_s2t_kernel<16>, hgrid, dim3(512), 0, stream, P);
+    }
     RIED_CHECK_LAUNCH("ried_conv2d");
     return RIED_OK;
   }
+  RIED_CHECK_ARG(!fold, "ried_conv2d_s2_dgrad_c1fold: needs a 3x3 stride-2 layer on maps of whole 16 x 16 tiles");
   // ConvTranspose2d(4, 2, 1) forward on maps of whole 16x16 tiles: all four phases of a tile in one block
   if (!xf && g_forced_tile[0] == 0 && P.E.staged && transposed && kh == 4 && kw == 4 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
       Ho == 2 * H && Wo == 2 * W && Cin % 32 == 0 && H % 16 == 0 && W % 16 == 0 && a_bytes < 0xFFFF0000ll - 16384 &&
@@ -2352,6 +2486,29 @@ extern "C" int ried_conv2d_signs(const void* x, long long ldx, const void* w, vo
   return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, bias, act,
                      stats, accumulate, 0, nullptr, 0, signs, ldsigns, mask_slope, stats_post, nullptr, stream, nullptr, 0,
                      nullptr, 0, 0.f, nullptr, nullptr, 1);
+}
+
+// Backward of the discriminator's second layer into its first (src/rinet.py:20-21) when only parameter gradients are
+// wanted: the data gradient of the 3x3 stride-2 convolution (dy: [nimg][H][W] with Cin channels, wt: its packed
+// transposed weights [64][3][3][Cin]) is masked with the first layer's LeakyReLU (mask: its output as bf16 view, or
+// its sign bytes when mask_bits = 1), its column sums go to stats (the first layer's bias gradient, stats_post = 1
+// rows) and its product with the nine taps of the first layer's fp32 input ximg [nimg][2H][2W] (used as
+// ximg * in_scale + in_shift, zero padded) is ADDED to dw [64][9] - the first layer's weight gradient - without the
+// masked gradient ever being written.  H, W multiples of 16; scratch: fp32 [ried_conv2d_s2_dgrad_c1fold_scratch_floats].
+extern "C" long long ried_conv2d_s2_dgrad_c1fold_scratch_floats(int nimg, int H, int W) {
+  return (long long)nimg * (H / 16) * (W / 16) * 64 * 9;
+}
+extern "C" int ried_conv2d_s2_dgrad_c1fold(const void* dy, long long lddy, const void* wt, int nimg, int H, int W,
+                                           int Cin, const void* mask, long long ldmask, int mask_bits,
+                                           float mask_slope, float* stats, const float* ximg, float in_scale,
+                                           float in_shift, float* dw, float* scratch, hipStream_t stream) {
+  RIED_CHECK_ARG(ximg && dw && scratch && mask && H % 16 == 0 && W % 16 == 0, "ried_conv2d_s2_dgrad_c1fold: bad arguments");
+  ConvFold f{ximg, in_scale, in_shift, scratch};
+  int rc = conv2d_impl(dy, lddy, wt, nullptr, 64, nimg, H, W, Cin, 2 * H, 2 * W, 64, 3, 3, 2, 2, 1, 1, 1, nullptr, 0,
+                       stats, 0, 0, nullptr, 0, mask, ldmask, mask_slope, 1, nullptr, stream, nullptr, 0, nullptr, 0, 0.f,
+                       nullptr, nullptr, mask_bits, &f);
+  if (rc != RIED_OK) return rc;
+  return ried_rows_add(scratch, nimg * (H / 16) * (W / 16), 64 * 9, dw, stream);
 }
 
 // ried_conv2d whose input x is the RAW convolution output of a BasicConv2d layer (src/rinet.py:183-205): the kernel

@@ -252,6 +252,14 @@ __global__ __launch_bounds__(1024) void rows_add_kernel(const float* __restrict_
   }
 }
 
+// out[c] += sum over r < nrows of part[r][c], c < width (partial rows that blocks wrote without atomics)
+extern "C" int ried_rows_add(const float* part, int nrows, int width, float* out, hipStream_t stream) {
+  RIED_CHECK_ARG(part && out && nrows > 0 && width > 0, "ried_rows_add: bad arguments");
+  hipLaunchKernelGGL(rows_add_kernel, dim3(ceil_div(width, 32)), dim3(1024), 0, stream, part, nrows, width, out);
+  RIED_CHECK_LAUNCH("ried_rows_add");
+  return RIED_OK;
+}
+
 #define C1_WGRAD_MAX_ROWS 512
 // dw[Cout][9] += weight gradient.  scratch: fp32 [ried_conv_c1_wgrad_scratch_floats(Cout)].
 extern "C" int ried_conv_c1_wgrad(const float* x, const void* dy, long long lddy, int nimg, int H, int W, int Cout,

@@ -1268,6 +1268,9 @@ def _chain(ctx: Ctx, seq: Seq, prefix: str, specs, xin: Slot, out: Slot, deconv=
 # The discriminator's first layer also writes one sign bit per activation and the second layer's data gradient reads
 # those for the LeakyReLU backward instead of the 64-channel activation itself (RIED_SIGN_MASK=0: the activation).
 SIGN_MASK = os.environ.get("RIED_SIGN_MASK", "1") != "0"
+# A discriminator backward pass that wants parameter gradients only forms the first layer's weight gradient inside the
+# second layer's data-gradient kernel and never stores the gradient of the first activation (RIED_C1_FOLD=0: off).
+C1_FOLD = os.environ.get("RIED_C1_FOLD", "1") != "0"
 XF_FUSE_MODE = os.environ.get("RIED_XF_FUSE", "s2")
 XF_FUSE = XF_FUSE_MODE not in ("", "0")
 
@@ -1600,6 +1603,9 @@ class SNConv:
             ctx.need_f32(ops.colsum_scratch_floats(cout))
             if first:
                 ctx.need_f32(ops.conv_c1_wgrad_scratch_floats(cout))
+                if C1_FOLD and cout == 64 and stride == 1 and Ho % 32 == 0 and Wo % 32 == 0:
+                    ctx.need_f32(ops.conv2d_s2_dgrad_c1fold_scratch_floats(N, Ho // 2, Wo // 2))
+                    self.foldable = True
             out.act.fuse_slope = 0.2          # whoever writes out.g may apply this layer's LeakyReLU backward
             if first and SIGN_MASK and cout % 8 == 0 and (out.c0, out.c1, out.n0, out.n1) == (0, cout, 0, N):
                 out.act.signs = torch.empty(N * Ho * Wo, cout // 8, dtype=torch.uint8, device=dev)
@@ -1610,6 +1616,12 @@ class SNConv:
         ctx.sn.add(st.p[prefix + ".weight_orig"], st.b[prefix + ".weight_u"], st.b[prefix + ".weight_v"], self.sigma,
                    cout, self.K, self.dwsn, st.g[prefix + ".weight_orig"] if ctx.grads else None)
         self.x_img: Optional[torch.Tensor] = None
+        # Set on the layer above a foldable first layer (by Discriminator): when a backward pass wants parameter
+        # gradients only, that layer's data gradient forms this layer's weight gradient in its epilogue and never
+        # stores the gradient of this layer's output (ops.conv2d_s2_dgrad_c1fold).
+        self.foldable = getattr(self, "foldable", False)
+        self.below: Optional["SNConv"] = None
+        self._folded = False
 
     def forward(self, x_img: Optional[torch.Tensor] = None, n0: int = 0, n1: Optional[int] = None):
         """Images [n0, n1) only (the layer has no statistics across the batch: halves may run at different times)."""
@@ -1644,7 +1656,9 @@ class SNConv:
             if wgrad:
                 ops.colsum(dpre, st.g[p + ".bias"], ctx.f32)
         if wgrad:
-            if self.first:
+            if self.first and self._folded:      # the layer above has already added this pass's sums to dwsn
+                self._folded = False
+            elif self.first:
                 self.dwsn.zero_()
                 ops.conv_c1_wgrad(self.x_img[n0:n1], dpre, self.stride, self.dwsn, ctx.f32)
             else:
@@ -1656,7 +1670,15 @@ class SNConv:
             xin = self.core.xin.images(n0, n1)
             xf = self.core.xin.act.fused
             sg = self.core.xin.act.signs
-            if xf is not None and sg is not None:
+            lo = self.below
+            if (xf is not None and lo is not None and wgrad and dimg is None and self.stride == 2 and
+                    (xin.c0, xin.c1) == (0, 64) and xin.shape[0] == lo.out.shape[0]):
+                hw = xin.shape[1] * xin.shape[2]
+                lo.dwsn.zero_()
+                ops.conv2d_s2_dgrad_c1fold(dpre, self.core.wpt, xin.v if sg is None else sg[xin.n0 * hw:xin.n1 * hw],
+                                           self.core.xin.act.fuse_slope, xf.stats, lo.x_img[n0:n1], lo.dwsn, ctx.f32)
+                lo._folded = True
+            elif xf is not None and sg is not None:
                 c, hw = self.core, xin.shape[1] * xin.shape[2]
                 assert (xin.c0, xin.c1) == (0, sg.shape[1] * 8)
                 ops.conv2d_signs(dpre, c.wpt, xin.g, c.kh, c.kw, c.sh, c.sw, c.ph, c.pw, sg[xin.n0 * hw:xin.n1 * hw],
@@ -1821,6 +1843,8 @@ class Discriminator:
             Attn(ctx, p + "5", 512, a4, a5),
             SNConv(ctx, p + "6.conv2d", 512, 512, 2, a5, a6),
         ]
+        if self.layers[0].foldable:
+            self.layers[1].below = self.layers[0]
         ctx.chain = True         # every gradient buffer has exactly one first writer that overwrites it
         ctx.finalize()
         self.out_features = 512 * (H // 16) * (W // 16)

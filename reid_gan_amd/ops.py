@@ -94,6 +94,34 @@ def conv2d_signs(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, sign
                           int(stats_post), _stream())
 
 
+def conv2d_s2_dgrad_c1fold_scratch_floats(nimg, H, W) -> int:
+    return lib.ried_conv2d_s2_dgrad_c1fold_scratch_floats(nimg, H, W)
+
+
+def conv2d_s2_dgrad_c1fold(dy: View, wt: torch.Tensor, mask, mask_slope: float, stats: Optional[torch.Tensor],
+                           ximg: torch.Tensor, dw: torch.Tensor, scratch: torch.Tensor, in_scale=1.0, in_shift=0.0):
+    """Data gradient of a 3x3 stride-2 layer into the 64-channel output of a one-input-channel first layer, consumed
+    in place: stats rows get the masked gradient's column sums, dw [64][9] += the first layer's weight gradient from
+    its fp32 input ximg (nimg, 1, 2H, 2W); the gradient itself is not stored.  mask: the first layer's output (View)
+    or its sign bytes (uint8 tensor [pixels][8])."""
+    n, h, w = dy.N, dy.H, dy.W
+    assert ximg.dtype == torch.float32 and ximg.is_contiguous() and ximg.numel() == n * 4 * h * w
+    assert dw.numel() == 64 * 9 and scratch.numel() >= conv2d_s2_dgrad_c1fold_scratch_floats(n, h, w)
+    if isinstance(mask, View):
+        assert (mask.N, mask.H, mask.W, mask.C) == (n, 2 * h, 2 * w, 64)
+        mp, ml, bits = mask.ptr, mask.ld, 0
+    else:
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == n * 4 * h * w * 8
+        mp, ml, bits = _p(mask), 8, 1
+    lib.ried_conv2d_s2_dgrad_c1fold(dy.ptr, dy.ld, _p(wt), n, h, w, dy.C, mp, ml, bits, mask_slope, _p(stats), _p(ximg),
+                                    in_scale, in_shift, _p(dw), _p(scratch), _stream())
+
+
+def rows_add(part: torch.Tensor, nrows: int, width: int, out: torch.Tensor):
+    """out[c] += sum over the first nrows rows of part[r][c]."""
+    lib.ried_rows_add(_p(part), nrows, width, _p(out), _stream())
+
+
 def conv2d_xf(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, xf_save, xf_gamma, xf_beta, xf_act=1,
               transposed=False, bias=None, act=0, stats=None, accumulate=False, stats_post=False):
     """conv2d on act(batchnorm(x)) with x the raw convolution output of the producing layer (save = its mean /

@@ -506,6 +506,50 @@ def test_conv2d_activation_backward_from_sign_bytes(cin, cout, s, slope, N, H):
     assert torch.equal(outs[0][1], outs[1][1])
 
 
+@pytest.mark.parametrize("cin,N,H,W,bits", [(128, 2, 16, 16, True), (128, 3, 32, 16, False), (64, 1, 16, 48, True)])
+def test_stride2_data_gradient_with_the_first_layer_weight_gradient_folded(cin, N, H, W, bits):
+    """ried_conv2d_s2_dgrad_c1fold against the two launches it replaces (masked data gradient stored, then
+    ried_conv_c1_wgrad on it) and against torch: the bias sums are identical, the weight gradient differs only by the
+    summation order and by the image being carried as two bf16 parts (16 mantissa bits) instead of fp32."""
+    slope = 0.2
+    g = r(N, cin, H, W, seed=61)
+    w = r(cin, 64, 3, 3, seed=62, scale=(cin * 9) ** -0.5)
+    wt = pack(w.permute(1, 0, 2, 3))
+    yact = r(N, 64, 2 * H, 2 * W, seed=63)
+    ximg = (torch.randn(N, 1, 2 * H, 2 * W, generator=torch.Generator().manual_seed(64)) * 300 - 200).to(DEV)
+    rows = ops.conv2d_stat_rows(N, 2 * H, 2 * W, cin, 64, 3, 3, 2, 2, True)
+    mask = _sign_bytes(yact).to(DEV).contiguous() if bits else to_view(yact)
+    # the two launches
+    yv = ops.new_view(N, 2 * H, 2 * W, 64)
+    stats_a = torch.full((rows, 2, 64), float("nan"), device=DEV)
+    if bits:
+        ops.conv2d_signs(to_view(g), wt, yv, 3, 3, 2, 2, 1, 1, mask, transposed=True, mask_slope=slope, stats=stats_a,
+                         stats_post=True)
+    else:
+        ops.conv2d(to_view(g), wt, yv, 3, 3, 2, 2, 1, 1, transposed=True, mask=mask, mask_slope=slope, stats=stats_a,
+                   stats_post=True)
+    dw_a = torch.zeros(64, 9, device=DEV)
+    scr = torch.full((ops.conv_c1_wgrad_scratch_floats(64),), float("nan"), device=DEV)
+    ops.conv_c1_wgrad(ximg, yv, 1, dw_a, scr, in_scale=1 / 512.0, in_shift=0.3)
+    # the fold
+    stats_b = torch.full((rows, 2, 64), float("nan"), device=DEV)
+    dw_b = torch.full((64, 9), 0.5, device=DEV)
+    scr2 = torch.full((ops.conv2d_s2_dgrad_c1fold_scratch_floats(N, H, W),), float("nan"), device=DEV)
+    ops.conv2d_s2_dgrad_c1fold(to_view(g), wt, mask, slope, stats_b, ximg, dw_b, scr2, in_scale=1 / 512.0, in_shift=0.3)
+    ba, bb = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    ops.stat_rows_sum(stats_a, rows, 64, ba)
+    ops.stat_rows_sum(stats_b, rows, 64, bb)
+    assert torch.equal(ba, bb)
+    close(dw_b.cpu() - 0.5, dw_a.cpu(), 2e-4, "folded weight gradient vs two launches")
+    # torch: the masked gradient rounded to bf16 as both paths do, then the first layer's weight gradient in fp32
+    da = F.conv_transpose2d(g, w, None, 2, 1, output_padding=1) * torch.where(yact > 0, 1.0, slope)
+    da = da.to(torch.bfloat16).float()
+    xa = (ximg.cpu() / 512.0 + 0.3).requires_grad_(False)
+    w0 = torch.zeros(64, 1, 3, 3, requires_grad=True)
+    (gw,) = torch.autograd.grad(F.conv2d(xa, w0, None, 1, 1), w0, da)
+    close(dw_b.cpu().reshape(64, 1, 3, 3) - 0.5, gw, 2e-3, "folded weight gradient vs torch")
+
+
 def test_maxpool_bwd_overwrite_and_relu_mask():
     x = r(2, 16, 8, 8, seed=51)
     xr = x.clone().requires_grad_(True)
