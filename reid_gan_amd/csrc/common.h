@@ -42,7 +42,12 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;                                          // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
   return __builtin_bit_cast(bf16_t, b);
 }
-__device__ __forceinline__ unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+// both values in ONE v_cvt_pk_bf16_f32 (two scalar conversions, a shift and an or take four instructions)
+typedef float pk_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2bf(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(pk_f32x2{lo, hi}, pk_bf16x2));
+}
 __device__ __forceinline__ float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 

@@ -24,6 +24,7 @@ __device__ __forceinline__ void unpack8s(const u32x4& v, float (&f)[8]) {
 // across the wave (scalar loads).  The bf16 results go through a padded LDS tile so that the global stores
 // are full 16-byte chunks in linear order instead of 64 scattered rows per instruction.
 #define C1_TILE 256
+typedef float c1_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void c1_taps(const float* __restrict__ x, long long p, long long npix, int H, int W, int Ho,
                                         int Wo, int stride, float in_scale, float in_shift, float (&xv)[9]) {
 #pragma unroll
@@ -48,39 +49,54 @@ __device__ __forceinline__ void c1_taps(const float* __restrict__ x, long long p
   }
 }
 
-template <int COUT>
+// ACT (0 none, 1 ReLU, 2 LeakyReLU 0.2), BIAS, STATS and SIGNS are compile-time: as run-time flags inside the
+// unrolled channel loop they became a scalar bias load with a full wait and three branches PER CHANNEL, a chain of
+// 64 dependent scalar-cache round trips per wave that bound the kernel.
+template <int COUT, int ACT, bool BIAS, bool STATS, bool SIGNS>
 __global__ __launch_bounds__(C1_TILE) void conv_c1_fwd_kernel(
     const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ sigma,
     const float* __restrict__ bias, bf16_t* __restrict__ y, long long ldy, int nimg, int H, int W, int Ho, int Wo,
-    int stride, float in_scale, float in_shift, int act, float* __restrict__ stats, unsigned char* __restrict__ signs) {
+    int stride, float in_scale, float in_shift, float* __restrict__ stats, unsigned char* __restrict__ signs) {
   constexpr int ROWB = COUT * 2 + 16;                 // bytes per pixel in the LDS tile (16 of padding)
   constexpr int CC = COUT / 8;
   __shared__ __attribute__((aligned(16))) char tile[C1_TILE * ROWB];
-  __shared__ float red[4][2 * COUT];
+  __shared__ float red[STATS ? 4 : 1][2 * COUT];
   const float inv = sigma ? 1.f / sigma[0] : 1.f;
   const long long npix = (long long)nimg * Ho * Wo;
   const long long p0 = (long long)blockIdx.x * C1_TILE;
   float xv[9];
   c1_taps(x, p0 + threadIdx.x, npix, H, W, Ho, Wo, stride, in_scale, in_shift, xv);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  unsigned sg[CC / 4];                                // one bit per channel: the stored value is positive
 #pragma unroll
-  for (int i = 0; i < CC / 4; ++i) sg[i] = 0u;
+  for (int t = 0; t < 9; ++t) xv[t] *= inv;           // 1/sigma on the nine inputs instead of the COUT sums
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned sg[SIGNS ? CC / 4 : 1];                    // one bit per channel: the stored value is positive
+#pragma unroll
+  for (int i = 0; i < (SIGNS ? CC / 4 : 1); ++i) sg[i] = 0u;
 #pragma unroll
   for (int cc = 0; cc < CC; ++cc) {
-    // The weights are indexed by compile-time constants off a kernel argument: they arrive through the scalar
-    // cache as SGPR operands of the FMAs (an LDS copy, broadcast-read 144 times per pixel, was what bound this
-    // kernel).  1/sigma is applied to the sums.
+    // The weights (and the bias) are indexed by compile-time constants off a kernel argument: they arrive through
+    // the scalar cache as SGPR operands of the FMAs (an LDS copy, broadcast-read 144 times per pixel, was what bound
+    // an earlier form).  The kernel is bound by vector-instruction issue, so eight of a channel's nine taps run as
+    // four packed FMAs on (tap, tap + 1) pairs - the pairs start at tap 0 for even channels and at tap 1 for odd ones,
+    // which keeps every weight pair on an even SGPR - and the two half sums are added at the end.
     float acc[8];
+    c1_f2 a2[8];                                      // the eight channels' chains side by side, not one after another
+    const float* wc = w + cc * 72;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const float* wq = w + (cc * 8 + q) * 9;
-      float a = 0.f;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) a += xv[t] * wq[t];
-      acc[q] = a * inv;
+    for (int q = 0; q < 8; ++q) {                     // o = q & 1: (cc * 8 + q) * 9 is odd exactly when q is
+      const int o = q & 1;
+      a2[q] = c1_f2{xv[o], xv[o + 1]} * c1_f2{wc[q * 9 + o], wc[q * 9 + o + 1]};
     }
-    if (stats) {      // per-channel sum and sum of squares of the raw results over the block's pixels
+#pragma unroll
+    for (int k = 1; k < 4; ++k)
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int o = q & 1;
+        a2[q] = c1_f2{xv[2 * k + o], xv[2 * k + o + 1]} * c1_f2{wc[q * 9 + 2 * k + o], wc[q * 9 + 2 * k + o + 1]} + a2[q];
+      }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = fmaf(xv[(q & 1) ? 0 : 8], wc[q * 9 + ((q & 1) ? 0 : 8)], a2[q][0] + a2[q][1]);
+    if constexpr (STATS) {      // per-channel sum and sum of squares of the raw results over the block's pixels
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         float s1 = wave_sum(acc[q]), s2 = wave_sum(acc[q] * acc[q]);      // out-of-range pixels hold zeros
@@ -89,19 +105,24 @@ __global__ __launch_bounds__(C1_TILE) void conv_c1_fwd_kernel(
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      float v = acc[q] + (bias ? bias[cc * 8 + q] : 0.f);
-      if (act == 1) v = fmaxf(v, 0.f);
-      else if (act == 2) v = v > 0.f ? v : 0.2f * v;
+      float v = acc[q];
+      if constexpr (BIAS) v += bias[cc * 8 + q];
+      if constexpr (ACT == 1) v = fmaxf(v, 0.f);
+      else if constexpr (ACT == 2) v = fmaxf(v, 0.2f * v);           // = v > 0 ? v : 0.2 v
       acc[q] = v;
-      sg[cc / 4] |= (v > 0.f ? 1u : 0u) << ((cc & 3) * 8 + q);
+      // 0 - v has its sign bit set exactly when v > 0 (both zeros give +0); one funnel shift moves it into the
+      // word, most significant bit first, and the word is reversed once at the end
+      if constexpr (SIGNS) sg[cc / 4] = __builtin_amdgcn_alignbit(sg[cc / 4], __float_as_uint(0.f - v), 31);
     }
     *reinterpret_cast<u32x4*>(tile + threadIdx.x * ROWB + cc * 16) =
         u32x4{pack2bf(acc[0], acc[1]), pack2bf(acc[2], acc[3]), pack2bf(acc[4], acc[5]), pack2bf(acc[6], acc[7])};
   }
-  if (signs && p0 + threadIdx.x < npix) {               // CC bytes per pixel, consecutive lanes consecutive pixels
-    unsigned* sp = reinterpret_cast<unsigned*>(signs + (p0 + threadIdx.x) * CC);
-    if constexpr (CC == 8) *reinterpret_cast<u32x2*>(sp) = u32x2{sg[0], sg[1]};
-    else sp[0] = sg[0];
+  if constexpr (SIGNS) {
+    if (p0 + threadIdx.x < npix) {                    // CC bytes per pixel, consecutive lanes consecutive pixels
+      unsigned* sp = reinterpret_cast<unsigned*>(signs + (p0 + threadIdx.x) * CC);
+      if constexpr (CC == 8) *reinterpret_cast<u32x2*>(sp) = u32x2{__builtin_bitreverse32(sg[0]), __builtin_bitreverse32(sg[1])};
+      else sp[0] = __builtin_bitreverse32(sg[0]);
+    }
   }
   __syncthreads();
 #pragma unroll
@@ -111,30 +132,53 @@ __global__ __launch_bounds__(C1_TILE) void conv_c1_fwd_kernel(
     if (p0 + px < npix)
       *reinterpret_cast<u32x4*>(y + (p0 + px) * ldy + cc * 8) = *reinterpret_cast<const u32x4*>(tile + px * ROWB + cc * 16);
   }
-  if (stats) {
+  if constexpr (STATS) {
     float* row = stats + (long long)blockIdx.x * 2 * COUT;        // one partial row per block (no global atomics)
     for (int i = threadIdx.x; i < 2 * COUT; i += C1_TILE) row[i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
   }
+}
+
+struct C1Args {
+  const float *x, *w, *sigma, *bias; bf16_t* y; long long ldy; int nimg, H, W, Ho, Wo, stride; float in_scale, in_shift;
+  float* stats; unsigned char* signs; int grid; hipStream_t stream;
+};
+template <int COUT, int ACT, bool BIAS, bool STATS, bool SIGNS>
+static void c1_launch(const C1Args& a) {
+  hipLaunchKernelGGL((conv_c1_fwd_kernel<COUT, ACT, BIAS, STATS, SIGNS>), dim3(a.grid), dim3(C1_TILE), 0, a.stream, a.x,
+                     a.w, a.sigma, a.bias, a.y, a.ldy, a.nimg, a.H, a.W, a.Ho, a.Wo, a.stride, a.in_scale, a.in_shift,
+                     a.stats, a.signs);
+}
+template <int COUT, int ACT>
+static void c1_dispatch(const C1Args& a) {
+  const bool b = a.bias != nullptr, st = a.stats != nullptr;
+  if (a.signs) {                     // (sign bytes only without statistics: the discriminator's first layer)
+    if (b) c1_launch<COUT, ACT, true, false, true>(a); else c1_launch<COUT, ACT, false, false, true>(a);
+  } else if (b && st) c1_launch<COUT, ACT, true, true, false>(a);
+  else if (b) c1_launch<COUT, ACT, true, false, false>(a);
+  else if (st) c1_launch<COUT, ACT, false, true, false>(a);
+  else c1_launch<COUT, ACT, false, false, false>(a);
 }
 
 static int conv_c1_fwd_impl(const float* x, const float* w, const float* sigma, const float* bias, void* y,
                             long long ldy, int nimg, int H, int W, int Cout, int stride, float in_scale,
                             float in_shift, int act, float* stats, unsigned char* signs, hipStream_t stream) {
   RIED_CHECK_ARG(x && w && y && nimg > 0 && H > 0 && W > 0, "ried_conv_c1_fwd: bad arguments");
-  RIED_CHECK_ARG(((uintptr_t)signs % 8) == 0, "ried_conv_c1_fwd_signs: the sign bytes must be 8-byte aligned");
+  RIED_CHECK_ARG(((uintptr_t)signs % 8) == 0 && !(signs && stats),
+                 "ried_conv_c1_fwd_signs: the sign bytes must be 8-byte aligned (and exclude statistics)");
   RIED_CHECK_ARG(stride == 1 || stride == 2, "ried_conv_c1_fwd: stride must be 1 or 2");
   RIED_CHECK_ARG(ldy % 8 == 0 && ldy >= Cout && ((uintptr_t)y % 16) == 0, "ried_conv_c1_fwd: output view");
   RIED_CHECK_ARG(Cout == 32 || Cout == 64, "ried_conv_c1_fwd: Cout must be 32 or 64 (got %d)", Cout);
+  RIED_CHECK_ARG(act >= 0 && act <= 2, "ried_conv_c1_fwd: act must be 0, 1 or 2");
   RIED_CHECK_ARG((long long)H * W < (1ll << 31), "ried_conv_c1_fwd: image too large");
   int Ho = (H + 2 - 3) / stride + 1, Wo = (W + 2 - 3) / stride + 1;
   long long npix = (long long)nimg * Ho * Wo;
-  int grid = ceil_div(npix, C1_TILE);
-  if (Cout == 32)
-    hipLaunchKernelGGL(conv_c1_fwd_kernel<32>, dim3(grid), dim3(C1_TILE), 0, stream, x, w, sigma, bias,
-                       (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats, signs);
-  else
-    hipLaunchKernelGGL(conv_c1_fwd_kernel<64>, dim3(grid), dim3(C1_TILE), 0, stream, x, w, sigma, bias,
-                       (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, act, stats, signs);
+  C1Args a{x, w, sigma, bias, (bf16_t*)y, ldy, nimg, H, W, Ho, Wo, stride, in_scale, in_shift, stats, signs,
+           (int)ceil_div(npix, C1_TILE), stream};
+  if (Cout == 32) {
+    if (act == 0) c1_dispatch<32, 0>(a); else if (act == 1) c1_dispatch<32, 1>(a); else c1_dispatch<32, 2>(a);
+  } else {
+    if (act == 0) c1_dispatch<64, 0>(a); else if (act == 1) c1_dispatch<64, 1>(a); else c1_dispatch<64, 2>(a);
+  }
   RIED_CHECK_LAUNCH("ried_conv_c1_fwd");
   return RIED_OK;
 }
