@@ -392,19 +392,29 @@ static inline int chan_grid(long long npix, int C, int iters, int cap) {
 }
 
 // Activation after BatchNorm: 0 none, 1 ReLU (src/rinet.py:188,200), 2 LeakyReLU(0.2) and 3 Sigmoid (the legacy
-// discriminator, src/networks.py:533-542).  The codes other than 0 / 1 take the slow branch.
-__device__ __forceinline__ float bn_act(float v, int act) {
-  if (act == 1) return fmaxf(v, 0.f);
-  if (act == 2) return v > 0.f ? v : 0.2f * v;
-  if (act == 3) return 1.f / (1.f + __expf(-v));
-  return v;
+// discriminator, src/networks.py:533-542).  Codes 0-2 are max(v, slope * v) with slope 1, 0, 0.2 - no branches (as
+// per-element tests of the run-time code these were three scalar branches per value in kernels whose whole run is a
+// few dependent round trips); the sigmoid is one uniform branch per eight values.
+__device__ __forceinline__ float act_slope(int act) { return act == 1 ? 0.f : (act == 2 ? 0.2f : 1.f); }
+// v -> act(v); sl = act_slope(act)
+__device__ __forceinline__ void bn_act8(float (&v)[8], int act, float sl) {
+  if (act == 3) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = 1.f / (1.f + __expf(-v[q]));
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = fmaxf(v[q], sl * v[q]);
+  }
 }
-// g * act'(v), v the pre-activation value
-__device__ __forceinline__ float bn_act_grad(float v, float g, int act) {
-  if (act == 1) return v > 0.f ? g : 0.f;
-  if (act == 2) return v > 0.f ? g : 0.2f * g;
-  if (act == 3) { float s = 1.f / (1.f + __expf(-v)); return g * s * (1.f - s); }
-  return g;
+// g -> g * act'(v), v the pre-activation values
+__device__ __forceinline__ void bn_act_grad8(const float (&v)[8], float (&g)[8], int act, float sl) {
+  if (act == 3) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { float t = 1.f / (1.f + __expf(-v[q])); g[q] *= t * (1.f - t); }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g[q] *= v[q] > 0.f ? 1.f : sl;
+  }
 }
 
 // y = act(gamma*(x-mean)*invstd + beta) [+ y]
@@ -419,6 +429,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
   y += (long long)blockIdx.y * npix * ldy;
   save += (long long)blockIdx.y * 2 * C;
   const int c = w.c;
+  const float sl = act_slope(relu);
   float a[8], b[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) {
@@ -427,13 +438,16 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_kernel(
   }
 #pragma unroll 2
   for (long long p = w.p; p < npix; p += w.step) {
-    float f[8], o[8];
+    float f[8];
     unpack8(ld8(x + p * ldx + c), f);
-    if (accumulate) unpack8(ld8(y + p * ldy + c), o);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float v = bn_act(f[q] * a[q] + b[q], relu);
-      f[q] = accumulate ? v + o[q] : v;
+    for (int q = 0; q < 8; ++q) f[q] = f[q] * a[q] + b[q];
+    bn_act8(f, relu, sl);
+    if (accumulate) {
+      float o[8];
+      unpack8(ld8(y + p * ldy + c), o);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] += o[q];
     }
     st8(y + p * ldy + c, pack8(f));
   }
@@ -506,6 +520,7 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
   __shared__ int last_flag;
   ChanWalk w(C);
   const int c = w.c;
+  const float sl = act_slope(relu);
   float s1[8], s2[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
@@ -521,12 +536,12 @@ __device__ __forceinline__ void bn_bwd_reduce_body(
       float g[8], xv[8];
       unpack8(ld8(dy + p * lddy + c), g);
       unpack8(ld8(x + p * ldx + c), xv);
+      float pre[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float d = xv[q] - mean[q];
-        float gg = bn_act_grad(d * a[q] + b[q], g[q], relu);
-        s1[q] += gg; s2[q] += gg * (d * istd[q]);
-      }
+      for (int q = 0; q < 8; ++q) { xv[q] -= mean[q]; pre[q] = xv[q] * a[q] + b[q]; }
+      bn_act_grad8(pre, g, relu, sl);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { s1[q] += g[q]; s2[q] += g[q] * (xv[q] * istd[q]); }
     }
   }
 #pragma unroll
@@ -568,6 +583,7 @@ __device__ __forceinline__ void bn_bwd_apply_body(
   ChanWalk w(C);
   if (!w.active) return;
   const int c = w.c;
+  const float sl = act_slope(relu);
   const float invn = 1.f / (float)npix;
   // the first two pixels of the walk are fetched together with the sums, not after them (see bn_apply_train_body)
   u32x4 pg[2], px[2];
@@ -605,12 +621,12 @@ __device__ __forceinline__ void bn_bwd_apply_body(
       float g[8], xv[8];
       unpack8(pg[k], g);
       unpack8(px[k], xv);
+      float pre[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float d = xv[q] - mean[q];
-        float gg = bn_act_grad(d * a[q] + b[q], g[q], relu);
-        g[q] = a[q] * (gg - m1[q] - d * istd[q] * m2[q]);
-      }
+      for (int q = 0; q < 8; ++q) { xv[q] -= mean[q]; pre[q] = xv[q] * a[q] + b[q]; }
+      bn_act_grad8(pre, g, relu, sl);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g[q] = a[q] * (g[q] - m1[q] - xv[q] * istd[q] * m2[q]);
       st8(dx + p * lddx + c, pack8(g));
     }
   }
@@ -619,12 +635,12 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     float g[8], xv[8];
     unpack8(ld8(dy + p * lddy + c), g);
     unpack8(ld8(x + p * ldx + c), xv);
+    float pre[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float d = xv[q] - mean[q];
-      float gg = bn_act_grad(d * a[q] + b[q], g[q], relu);
-      g[q] = a[q] * (gg - m1[q] - d * istd[q] * m2[q]);
-    }
+    for (int q = 0; q < 8; ++q) { xv[q] -= mean[q]; pre[q] = xv[q] * a[q] + b[q]; }
+    bn_act_grad8(pre, g, relu, sl);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) g[q] = a[q] * (g[q] - m1[q] - xv[q] * istd[q] * m2[q]);
     st8(dx + p * lddx + c, pack8(g));
   }
 }
@@ -715,6 +731,7 @@ __device__ __forceinline__ void bn_bwd_fused_body(
   __shared__ float red[EW_THREADS][17];
   ChanWalk w(C);
   const int c = w.c;
+  const float sl = act_slope(relu);
   float s1[8], s2[8], a[8], b[8], mean[8], istd[8];
   float kg[KEEP ? KEEP : 1][8], kx[KEEP ? KEEP : 1][8];
 #pragma unroll
@@ -735,14 +752,19 @@ __device__ __forceinline__ void bn_bwd_fused_body(
 #pragma unroll
       for (int k = 0; k < KEEP; ++k) {
         const long long p = w.p + k * w.step;
-        float g[8], xv[8];
+        float g[8], xv[8], pre[8];
         if (p < npix) { unpack8(vg[k], g); unpack8(vx[k], xv); }
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          float d = p < npix ? xv[q] - mean[q] : 0.f;
-          float gg = p < npix ? bn_act_grad(d * a[q] + b[q], g[q], relu) : 0.f;
-          kg[k][q] = gg; kx[k][q] = d * istd[q];
-          s1[q] += gg; s2[q] += gg * kx[k][q];
+          xv[q] = p < npix ? xv[q] - mean[q] : 0.f;
+          g[q] = p < npix ? g[q] : 0.f;
+          pre[q] = xv[q] * a[q] + b[q];
+        }
+        bn_act_grad8(pre, g, relu, sl);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          kg[k][q] = g[q]; kx[k][q] = xv[q] * istd[q];
+          s1[q] += g[q]; s2[q] += g[q] * kx[k][q];
         }
       }
     } else {
@@ -751,12 +773,12 @@ __device__ __forceinline__ void bn_bwd_fused_body(
         float g[8], xv[8];
         unpack8(ld8(dy + p * lddy + c), g);
         unpack8(ld8(x + p * ldx + c), xv);
+        float pre[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          float d = xv[q] - mean[q];
-          float gg = bn_act_grad(d * a[q] + b[q], g[q], relu);
-          s1[q] += gg; s2[q] += gg * (d * istd[q]);
-        }
+        for (int q = 0; q < 8; ++q) { xv[q] -= mean[q]; pre[q] = xv[q] * a[q] + b[q]; }
+        bn_act_grad8(pre, g, relu, sl);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s1[q] += g[q]; s2[q] += g[q] * (xv[q] * istd[q]); }
       }
     }
   }
@@ -806,12 +828,12 @@ __device__ __forceinline__ void bn_bwd_fused_body(
       float g[8], xv[8];
       unpack8(ld8(dy + p * lddy + c), g);
       unpack8(ld8(x + p * ldx + c), xv);
+      float pre[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float d = xv[q] - mean[q];
-        float gg = bn_act_grad(d * a[q] + b[q], g[q], relu);
-        g[q] = a[q] * (gg - m1[q] - d * istd[q] * m2[q]);
-      }
+      for (int q = 0; q < 8; ++q) { xv[q] -= mean[q]; pre[q] = xv[q] * a[q] + b[q]; }
+      bn_act_grad8(pre, g, relu, sl);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g[q] = a[q] * (g[q] - m1[q] - xv[q] * istd[q] * m2[q]);
       st8(dx + p * lddx + c, pack8(g));
     }
   }
@@ -1077,6 +1099,7 @@ __device__ __forceinline__ void bn_apply_train_body(
   __syncthreads();
   if (!w.active) return;
   const int c = w.c;
+  const float sl = act_slope(relu);
   float a[8], b[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) { a[q] = ab[0][w.cl * 8 + q]; b[q] = ab[1][w.cl * 8 + q]; }
@@ -1084,26 +1107,32 @@ __device__ __forceinline__ void bn_apply_train_body(
   for (int k = 0; k < 2; ++k) {
     const long long p = w.p + k * w.step;
     if (p < npix) {
-      float f[8], o[8];
+      float f[8];
       unpack8(px[k], f);
-      if (accumulate) unpack8(po[k], o);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        float v = bn_act(f[q] * a[q] + b[q], relu);
-        f[q] = accumulate ? v + o[q] : v;
+      for (int q = 0; q < 8; ++q) f[q] = f[q] * a[q] + b[q];
+      bn_act8(f, relu, sl);
+      if (accumulate) {
+        float o[8];
+        unpack8(po[k], o);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] += o[q];
       }
       st8(y + p * ldy + c, pack8(f));
     }
   }
 #pragma unroll 2
   for (long long p = w.p + 2 * w.step; p < npix; p += w.step) {
-    float f[8], o[8];
+    float f[8];
     unpack8(ld8(x + p * ldx + c), f);
-    if (accumulate) unpack8(ld8(y + p * ldy + c), o);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      float v = bn_act(f[q] * a[q] + b[q], relu);
-      f[q] = accumulate ? v + o[q] : v;
+    for (int q = 0; q < 8; ++q) f[q] = f[q] * a[q] + b[q];
+    bn_act8(f, relu, sl);
+    if (accumulate) {
+      float o[8];
+      unpack8(ld8(y + p * ldy + c), o);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] += o[q];
     }
     st8(y + p * ldy + c, pack8(f));
   }
