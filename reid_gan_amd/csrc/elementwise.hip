@@ -1724,9 +1724,51 @@ extern "C" int ried_ew(int op, const void* a, long long lda, const void* y, long
   return RIED_OK;
 }
 
-// column sums (bias gradients): per-block partial rows, then a row reduction; no global atomics
-__global__ void colsum_kernel(const bf16_t* __restrict__ a, long long lda, long long npix, int C,
-                              float* __restrict__ part) {
+// column sums (bias gradients): per-block partial rows, then a row reduction; no global atomics.
+// A thread owns one 8-channel chunk column and walks pixel rows (no index arithmetic in the loop, four loads in
+// flight); the block's pixel lanes are added through LDS.  C <= 8 * EW_THREADS.
+__global__ __launch_bounds__(EW_THREADS) void colsum_kernel(const bf16_t* __restrict__ a, long long lda, long long npix,
+                                                            int C, float* __restrict__ part) {
+  __shared__ float red[EW_THREADS][9];
+  ChanWalk w(C);
+  float s[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) s[q] = 0.f;
+  if (w.active) {
+    const bf16_t* src = a + w.c;
+    long long p = w.p;
+    for (; p + 3 * w.step < npix; p += 4 * w.step) {
+      u32x4 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = ld8(src + (p + k * w.step) * lda);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float f[8];
+        unpack8(v[k], f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s[q] += f[q];
+      }
+    }
+    for (; p < npix; p += w.step) {
+      float f[8];
+      unpack8(ld8(src + p * lda), f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s[q] += f[q];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) red[threadIdx.x][q] = s[q];
+  __syncthreads();
+  const int CC = C >> 3, PPB = EW_THREADS / CC;
+  for (int j = threadIdx.x; j < C; j += EW_THREADS) {
+    float t = 0.f;
+    for (int pl = 0; pl < PPB; ++pl) t += red[pl * CC + (j >> 3)][j & 7];
+    part[(long long)blockIdx.x * C + j] = t;
+  }
+}
+// the form for C > 8 * EW_THREADS: a thread's chunk column changes as it strides through the tensor
+__global__ void colsum_wide_kernel(const bf16_t* __restrict__ a, long long lda, long long npix, int C,
+                                   float* __restrict__ part) {
   extern __shared__ float lsum[];
   for (int i = threadIdx.x; i < C; i += blockDim.x) lsum[i] = 0.f;
   __syncthreads();
@@ -1752,18 +1794,22 @@ __global__ void colsum_kernel(const bf16_t* __restrict__ a, long long lda, long 
   __syncthreads();
   for (int j = threadIdx.x; j < C; j += blockDim.x) part[(long long)blockIdx.x * C + j] = lsum[j];
 }
-__global__ void colsum_finish_kernel(const float* __restrict__ part, int nrows, int C, float* __restrict__ out) {
-  __shared__ float sh[8][32];
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31), ty = threadIdx.x >> 5;
+// out[c] += sum over the rows of part[r][c]: 32 columns x 32 row lanes per block, the loads of a lane independent
+__global__ __launch_bounds__(1024) void colsum_finish_kernel(const float* __restrict__ part, int nrows, int C,
+                                                             float* __restrict__ out) {
+  __shared__ float sh[32][33];
+  const int cl = threadIdx.x & 31, ty = threadIdx.x >> 5, c = blockIdx.x * 32 + cl;
   float a = 0.f;
-  if (c < C)
-    for (int r = ty; r < nrows; r += 8) a += part[(long long)r * C + c];
-  sh[ty][threadIdx.x & 31] = a;
+  if (c < C) {
+#pragma unroll 8
+    for (int r = ty; r < nrows; r += 32) a += part[(long long)r * C + c];
+  }
+  sh[ty][cl] = a;
   __syncthreads();
   if (ty == 0 && c < C) {
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += sh[k][threadIdx.x & 31];
+    for (int k = 0; k < 32; ++k) t += sh[k][cl];
     out[c] += t;
   }
 }
@@ -1829,16 +1875,25 @@ extern "C" int ried_stat_rows_sum(const float* stats, int nrows, int C, float* o
 }
 
 #define COLSUM_MAX_ROWS 256
+// partial rows [grid][C] into scratch; returns grid
+static int colsum_launch(const bf16_t* a, long long lda, long long npix, int C, float* scratch, hipStream_t stream) {
+  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, COLSUM_MAX_ROWS);
+  if (C <= 8 * EW_THREADS) {
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(EW_THREADS), 0, stream, a, lda, npix, C, scratch);
+  } else {
+    if (grid * EW_THREADS < C / 8) grid = ceil_div(C / 8, EW_THREADS);
+    hipLaunchKernelGGL(colsum_wide_kernel, dim3(grid), dim3(EW_THREADS), C * sizeof(float), stream, a, lda, npix, C,
+                       scratch);
+  }
+  return grid;
+}
 // out[c] += sum_p a[p][c].  scratch: fp32 [COLSUM_MAX_ROWS * C].
 extern "C" int ried_colsum(const void* a, long long lda, long long npix, int C, float* out, float* scratch,
                            hipStream_t stream) {
   CHECK_VIEW("ried_colsum", a, lda, C);
   RIED_CHECK_ARG(out && scratch && npix > 0 && C <= 8192, "ried_colsum: bad arguments");
-  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, COLSUM_MAX_ROWS);
-  if (grid * EW_THREADS < C / 8) grid = ceil_div(C / 8, EW_THREADS);
-  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(EW_THREADS), C * sizeof(float), stream, (const bf16_t*)a, lda,
-                     npix, C, scratch);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, stream, scratch, grid, C, out);
+  int grid = colsum_launch((const bf16_t*)a, lda, npix, C, scratch, stream);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, scratch, grid, C, out);
   RIED_CHECK_LAUNCH("ried_colsum");
   return RIED_OK;
 }
@@ -1875,11 +1930,8 @@ extern "C" int ried_colsum_static(const void* a, long long lda, long long npix, 
   }
   // same grid and kernels as ried_colsum: rows [0, grid) of the scratch are fully overwritten for channels [0, C)
   // before the second kernel reads them, so what an earlier call left behind is never read
-  int grid = ew_grid(npix * (C / 8), EW_THREADS * 8, COLSUM_MAX_ROWS);
-  if (grid * EW_THREADS < C / 8) grid = ceil_div(C / 8, EW_THREADS);
-  hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(EW_THREADS), C * sizeof(float), stream, (const bf16_t*)a, lda,
-                     npix, C, scratch);
-  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 32)), dim3(256), 0, stream, scratch, grid, C, out);
+  int grid = colsum_launch((const bf16_t*)a, lda, npix, C, scratch, stream);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(C, 32)), dim3(1024), 0, stream, scratch, grid, C, out);
   RIED_CHECK_LAUNCH("ried_colsum_static");
   return RIED_OK;
 }

@@ -1176,6 +1176,18 @@ def test_misc_elementwise():
     close(back.cpu(), from_view(o), 1e-7, "nhwc->nchw")
 
 
+@pytest.mark.parametrize("N,C,H,W,c0", [(3, 640, 16, 16, 0), (2, 320, 8, 8, 64), (1, 8, 5, 7, 0), (5, 2048, 2, 3, 0),
+                                        (2, 4096, 2, 2, 0), (64, 512, 4, 4, 0), (1, 24, 1, 1, 8)])
+def test_column_sums(N, C, H, W, c0):
+    """ried_colsum on whole tensors and on channel slices of wider ones (chunk columns that do not divide the block,
+    fewer pixels than pixel lanes, more channels than one block's threads own)."""
+    wide = r(N, C + c0 + 8, H, W, seed=71)
+    v = to_view(wide).slice(c0, c0 + C)
+    cs = torch.full((C,), 0.25, device=DEV)
+    ops.colsum(v, cs, torch.full((ops.colsum_scratch_floats(C),), float("nan"), device=DEV))
+    close(cs.cpu() - 0.25, wide[:, c0:c0 + C].sum((0, 2, 3)), 1e-3, "colsum")
+
+
 def _ssim_ref(a, b, c1, c2):
     from oracle import ried_oracle as O
     return O.ssim_map(a, b, c1, c2)
