@@ -222,7 +222,8 @@ class TrainStep:
         self.close()
 
     def __del__(self):          # never destroy a graph from the garbage collector: park what close() did not see
-        _park_on_del(self)
+        if _park_on_del is not None:          # (None once the interpreter is tearing the module down)
+            _park_on_del(self)
 
     @property
     def exchange(self):
@@ -661,7 +662,8 @@ class InferenceEngine:
         self.close()
 
     def __del__(self):          # never destroy a graph from the garbage collector: park what close() did not see
-        _park_on_del(self)
+        if _park_on_del is not None:          # (None once the interpreter is tearing the module down)
+            _park_on_del(self)
 
     def measures(self, sums: torch.Tensor):
         """Per-slice ((psnr, ssim, rmse) original, (psnr, ssim, rmse) prediction) as Python floats."""
