@@ -599,10 +599,26 @@ __device__ __forceinline__ void bn_bwd_apply_body(
     a[q] = gamma[c + q] * istd[q]; b[q] = beta[c + q];
     m1[q] = sums[c + q]; m2[q] = sums[C + c + q];
   }
-  for (int r = 1; r < fold_rows; ++r) {           // the folded form: every thread adds the rows up for its channels
+  // the folded form: every thread adds the rows up for its channels - four rows' loads in flight at a time (one row
+  // per trip made the sums a chain of dependent round trips: most of this kernel's time on the small layers)
+  for (int r0 = 1; r0 < fold_rows; r0 += 4) {
+    f32x4 t[4][4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      m1[q] += sums[(long long)r * 2 * C + c + q]; m2[q] += sums[(long long)r * 2 * C + C + c + q];
+    for (int k = 0; k < 4; ++k) {
+      if (r0 + k < fold_rows) {
+        const float* row = sums + (long long)(r0 + k) * 2 * C + c;
+        t[k][0] = *reinterpret_cast<const f32x4*>(row);     t[k][1] = *reinterpret_cast<const f32x4*>(row + 4);
+        t[k][2] = *reinterpret_cast<const f32x4*>(row + C); t[k][3] = *reinterpret_cast<const f32x4*>(row + C + 4);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (r0 + k < fold_rows) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          m1[q] += t[k][0][q]; m1[4 + q] += t[k][1][q]; m2[q] += t[k][2][q]; m2[4 + q] += t[k][3][q];
+        }
+      }
     }
   }
   if (fold_rows && dgamma && w.p == 0) {          // ... and the first pixel's threads write the parameter gradients
@@ -1037,10 +1053,15 @@ __device__ __forceinline__ void slice_row_sums(const float* __restrict__ part, i
   const int k = col >= SW, ch = col - k * SW;
   if (rl < RL) {
     float a = 0.f;
-    if (c0 + ch < C) {
+    if (c0 + ch < C) {       // sixteen rows' loads in flight at a time (the folded form has 32 rows in all)
       const float* src = part + (long long)k * ldp + c0 + ch;
-#pragma unroll 4
-      for (int r = rl; r < nrows; r += RL) a += src[(long long)r * 2 * ldp];
+      for (int r = rl; r < nrows; r += 16 * RL) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = r + i * RL < nrows ? src[(long long)(r + i * RL) * 2 * ldp] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) a += v[i];
+      }
     }
     lds[rl * ncol + col] = a;
   }
