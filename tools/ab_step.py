@@ -1,11 +1,11 @@
 """A/B timing of the captured training step (batch 128 of 64x64) with engine switches flipped, in one process
 and interleaved (A B A B ...) so that box-to-box and warm-up drift cancel.
 usage: ab_step.py SWITCH[=value] [SWITCH[=value] ...]     e.g.  ab_step.py BN_BWD_ONE=1
-Each argument names a module constant of reid_gan_amd.engine; A is the default tree, B has all of them set."""
+Each argument names a module constant of reid_gan_amd.engine (or reid_gan_amd.train_step); A is the default tree, B has all of them set."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
-from reid_gan_amd import engine, ops
+from reid_gan_amd import engine, ops, train_step
 from reid_gan_amd.synth import synth_batch
 from reid_gan_amd.train_step import TrainStep
 
@@ -39,13 +39,14 @@ if __name__ == "__main__":
     ab_lookahead = "--ab-lookahead" in sys.argv      # A: plain plan, B: look-ahead plan
     for a in args:
         k, _, v = a.partition("=")
-        flips[k] = type(getattr(engine, k))(int(v)) if v else (not getattr(engine, k))
-    base = {k: getattr(engine, k) for k in flips}
+        mod = engine if hasattr(engine, k) else train_step
+        flips[k] = type(getattr(mod, k))(int(v)) if v else (not getattr(mod, k))
+    base = {k: getattr(engine if hasattr(engine, k) else train_step, k) for k in flips}
     res = {"A": [], "B": []}
     for rep in range(3):
         for name, vals in (("A", base), ("B", flips)):
             for k, v in vals.items():
-                setattr(engine, k, v)
+                setattr(engine if hasattr(engine, k) else train_step, k, v)
             if ab_lookahead:
                 LOOKAHEAD = name == "B"
             ms, losses = timed()
