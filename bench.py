@@ -50,6 +50,7 @@ def instrumented_step(ts):
     attention).  Returns (families, templates): time, flops and algorithmic bytes summed per kernel family and per
     kernel template (the template a call runs comes from ried_conv2d_which / the tile rules of the weight gradient)."""
     from reid_gan_amd import ops
+    from reid_gan_amd._lib import lib
     rec = []            # (family, template, flops, bytes, event, event)
     names = ("conv2d", "conv2d_tap_mse", "conv2d_wgrad", "bgemm", "attn_fwd", "attn_bwd")
     orig = {k: getattr(ops, k) for k in names}
@@ -80,7 +81,9 @@ def instrumented_step(ts):
     def wgrad(g, p, kh, kw_, sh, sw, ph, pw, slab, splitk):
         bm, bn = (64 if g.C <= 64 else 128), (64 if p.C <= 64 else 128)
         nb = 2.0 * (g.npix * g.C + p.npix * p.C) + 4.0 * splitk * kh * kw_ * p.C * g.C
-        timed("wgrad", f"wgrad_glds_kernel<{bm},{bn},2>", 2.0 * p.npix * p.C * g.C * kh * kw_, nb,
+        nt = lib.ried_conv2d_wgrad_taps_per_block(g.C, p.C, kh, kw_, p.npix)
+        timed("wgrad", f"wgrad_glds_kernel<{bm},{bn},2" + (f",{nt}>" if nt > 1 else ">"),
+              2.0 * p.npix * p.C * g.C * kh * kw_, nb,
               lambda: orig["conv2d_wgrad"](g, p, kh, kw_, sh, sw, ph, pw, slab, splitk))
 
     def bgemm(A, lda, bsa, a_tr, B, ldb, bsb, b_tr, M, N, K, batch, *a, **k):
@@ -102,8 +105,10 @@ def instrumented_step(ts):
     launch_wj, launch_cj = ops.WgradJobs.launch, ops.ConvJobs.launch      # the grouped launches of the generator
 
     def wj(self):
-        launch_wj(self, around=lambda bm, bn, fn: timed("wgrad", f"wgrad_glds_jobs_kernel<{bm},{bn},2>",
-                                                        self.group_flops[(bm, bn)], self.group_bytes[(bm, bn)], fn))
+        # (bn carries the jobs' taps per block above bit 16)
+        launch_wj(self, around=lambda bm, bn, fn: timed(
+            "wgrad", f"wgrad_glds_jobs_kernel<{bm},{bn & 0xFFFF},2" + (f",{(bn >> 16) + 1}>" if bn >> 16 else ">"),
+            self.group_flops[(bm, bn)], self.group_bytes[(bm, bn)], fn))
 
     def cj(self):
         timed("conv", "conv_glds_jobs_kernel<64,64,2>", self.flops, self.bytes, lambda: launch_cj(self))

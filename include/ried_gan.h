@@ -156,6 +156,12 @@ int ried_conv2d_which(const void* x, long long ldx, const void* w, void* y, long
                       const float* bias, int act, float* stats, int accumulate, int out_f32, float* y2, long long ldy2,
                       const void* mask, long long ldmask, float mask_slope, int stats_post, int* which);
 int ried_conv2d_wgrad_tiles(int Cg, int Cp); /* blocks per (tap, split) of ried_conv2d_wgrad: for choosing splitk */
+/* Taps of the kernel window one block of ried_conv2d_wgrad computes (layers with at most 64 gathered channels and
+ * enough output pixels npix = nimg * Ho * Wo: 3 of a 3 x 3 window, 2 of a 4 x 4 window; else 1): the grid has
+ * tiles * kh * kw / taps_per_block blocks per split.  For choosing splitk. */
+int ried_conv2d_wgrad_taps_per_block(int Cg, int Cp, int kh, int kw, long long npix);
+/* Tuning hook (no counterpart in the reference): on = 0 makes every later weight gradient one tap per block. */
+int ried_conv2d_wgrad_row_blocks(int on);
 /* out[tap*st + p*sp + g*sg] (+)= scale * sum over splits: scatters into the (Cout,Cin,kh,kw) or (Cin,Cout,kh,kw)
  * fp32 master gradient. */
 int ried_wgrad_reduce(const float* slab, int splitk, int taps, int Cp, int Cg, float* out, long long st, long long sp,

@@ -49,7 +49,7 @@ def _ctype_of(t: str):
     return _CTYPES[t]
 
 
-_VALUE_SUFFIXES = ("_rows", "_floats", "_version", "_cus", "_tiles", "_bytes", "_supported", "_ok")
+_VALUE_SUFFIXES = ("_rows", "_floats", "_version", "_cus", "_tiles", "_bytes", "_supported", "_ok", "_per_block")
 
 
 class _Lib:

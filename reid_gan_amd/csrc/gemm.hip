@@ -2013,21 +2013,26 @@ __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P
 // register-staged form on the discriminator's layers: 2-10 % faster with two stages; three stages (one block per
 // CU) are 40 % slower.
 // ---------------------------------------------------------------------------
-template <int BM, int BN, int NST>
+// NT > 1: a block owns the NT taps s0 .. s0 + NT - 1 of kernel row r0 (kw % NT == 0) and keeps one accumulator set
+// per tap.  A stage then holds NT gathered tiles and ONE tile of the pixel-indexed tensor, which serves all of them:
+// with few channels these kernels are bound by L2 -> LDS traffic (a 64 x 128 tile moves 24 KB per 64 pixels and tap),
+// and per tap the block now fetches (NT * A + B) / NT instead of A + B.  Grid: (tile, kh * kw / NT, k split).
+template <int BM, int BN, int NST, int NT = 1>
 __device__ __forceinline__ void wgrad_glds_body(const GemmParams& P, int bx, int by, int bz, int ntiles_n,
                                                 unsigned nblocks, char* smem) {
   using GA = TileGeom<BM>;
   using GB = TileGeom<BN>;
   constexpr int TM = BM / 32, TN = BN / 32;
-  constexpr int NCA = BM / 32, NCB = BN / 32;          // DMA loads per lane per stage and operand
-  constexpr int ASZ = BK * BM * 2, BSZ = BK * BN * 2, STAGE = ASZ + BSZ;
+  constexpr int NCA = BM / 32, NCB = BN / 32;          // DMA loads per lane per stage and operand tile
+  constexpr int ASZ = BK * BM * 2, BSZ = BK * BN * 2, STAGE = NT * ASZ + BSZ;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int tm = bx % P.tiles_m, tn = bx / P.tiles_m;
   const int m0 = tm * BM, n0 = tn * BN;
   const GemmOperand& G = P.A;
-  const int r0 = by / G.kw, s0 = by % G.kw;
+  const int gpr = G.kw / NT;                           // tap groups per kernel row
+  const int r0 = by / gpr, s0 = (by % gpr) * NT;
   const int per = ((P.K + P.splitk - 1) / P.splitk + BK - 1) / BK * BK;
   const int kbeg = bz * per, kend = min(P.K, kbeg + per);
   const int nsteps = (max(kend - kbeg, 0) + BK - 1) / BK;
@@ -2063,10 +2068,15 @@ __device__ __forceinline__ void wgrad_glds_body(const GemmParams& P, int bx, int
     char* dst = lds_wave + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < NCA; ++i) {
-      const int hi = gy[i] * G.sh - G.ph + r0, wi = gx[i] * G.sw - G.pw + s0;
-      const bool ok = kcur + kA + GA::KR * i < kend && (unsigned)hi < (unsigned)G.H && (unsigned)wi < (unsigned)G.W;
-      unsigned bad = ok ? 0u : GLDS_OOB;
-      glds16(rsA, ((unsigned)((gn[i] * G.H + hi) * G.W + wi) * ldg2 + colA) | bad | deadA, dst + i * 4096);
+      const int hi = gy[i] * G.sh - G.ph + r0, wi0 = gx[i] * G.sw - G.pw + s0;
+      const bool rok = kcur + kA + GA::KR * i < kend && (unsigned)hi < (unsigned)G.H;
+      const unsigned rowoff = (unsigned)((gn[i] * G.H + hi) * G.W + wi0) * ldg2 + colA;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const bool ok = rok && (unsigned)(wi0 + t) < (unsigned)G.W;
+        unsigned bad = ok ? 0u : GLDS_OOB;
+        glds16(rsA, (rowoff + (unsigned)t * ldg2) | bad | deadA, dst + t * ASZ + i * 4096);
+      }
       int x = gx[i] + dx, y = gy[i] + dy, n = gn[i] + dn;
       if (x >= G.Wo) { x -= G.Wo; ++y; }
       if (y >= G.Ho) { y -= G.Ho; ++n; }
@@ -2075,23 +2085,27 @@ __device__ __forceinline__ void wgrad_glds_body(const GemmParams& P, int bx, int
 #pragma unroll
     for (int i = 0; i < NCB; ++i) {
       unsigned bad = kcur + kB + GB::KR * i < kend ? 0u : GLDS_OOB;
-      glds16(rsB, boff[i] | bad | deadB, dst + ASZ + i * 4096);
+      glds16(rsB, boff[i] | bad | deadB, dst + NT * ASZ + i * 4096);
       boff[i] += (unsigned)BK * ldp2;
     }
     kcur += BK;
   };
 
-  f32x4 acc[TM][TN];
+  f32x4 acc[NT][TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   bf16x8_t fa[2][TM], fb[2][TN];
-  auto load_frags = [&](int buf, int ks) {
-    const bf16_t* sa = reinterpret_cast<const bf16_t*>(smem + buf * STAGE);
-    const bf16_t* sb = reinterpret_cast<const bf16_t*>(smem + buf * STAGE + ASZ);
+  auto load_a = [&](int buf, int t, int ks) {
+    const bf16_t* sa = reinterpret_cast<const bf16_t*>(smem + buf * STAGE + t * ASZ);
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[ks][i] = read_frag<OP_PLAIN_TR, BM>(sa, wm * (BM / 2) + i * 16, lane, ks);
+  };
+  auto load_b = [&](int buf, int ks) {
+    const bf16_t* sb = reinterpret_cast<const bf16_t*>(smem + buf * STAGE + NT * ASZ);
 #pragma unroll
     for (int j = 0; j < TN; ++j) fb[ks][j] = read_frag<OP_PLAIN_TR, BN>(sb, wn * (BN / 2) + j * 16, lane, ks);
   };
@@ -2099,29 +2113,38 @@ __device__ __forceinline__ void wgrad_glds_body(const GemmParams& P, int bx, int
   for (int st = 0; st < NST - 1; ++st) issue(st);
   int rd = 0, wr = NST - 1;
   for (int step = 0; step < nsteps; ++step) {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NCA + NCB)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NT * NCA + NCB)) : "memory");
     __builtin_amdgcn_s_barrier();
-    load_frags(rd, 0);
+    load_a(rd, 0, 0);
+    load_b(rd, 0);
     issue(wr);
-    load_frags(rd, 1);
+    load_a(rd, 0, 1);
+    load_b(rd, 1);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int t = 0; t < NT; ++t) {
+      if (t) { load_a(rd, t, 0); load_a(rd, t, 1); }
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[ks][i], fb[ks][j], acc[t][i][j], 0, 0, 0);
+    }
     rd = rd + 1 == NST ? 0 : rd + 1;
     wr = wr + 1 == NST ? 0 : wr + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  gemm_epilogue<BM, BN, true>(P, acc, m0, LinearRowMap{P, n0, 0, 0}, tn, 0, ntiles_n, by, bz, nblocks, smem);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    gemm_epilogue<BM, BN, true>(P, acc[t], m0, LinearRowMap{P, n0, 0, 0}, tn, 0, ntiles_n, r0 * G.kw + s0 + t, bz,
+                                nblocks, smem);
 }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, int NT = 1>
 __global__ __launch_bounds__(256) void wgrad_glds_kernel(const GemmParams P) {
-  __shared__ __attribute__((aligned(1024))) char smem[NST * BK * (BM + BN) * 2];
+  __shared__ __attribute__((aligned(1024))) char smem[NST * BK * (NT * BM + BN) * 2];
   // Workgroups go to the XCDs round-robin by their linear index (tile fastest, then tap, then k split), while the
   // blocks that read the same pixels are those of one k split: renumbered so that a split's blocks run on ONE XCD
   // (its pixels are fetched into one L2, not eight).  The splits beyond the last whole round of 8 keep their numbers.
@@ -2134,18 +2157,18 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const GemmParams P) {
     bx = w % (int)gridDim.x;
     by = w / (int)gridDim.x;
   }
-  wgrad_glds_body<BM, BN, NST>(P, bx, by, bz, gridDim.x / P.tiles_m, gridDim.x * gridDim.y * gridDim.z, smem);
+  wgrad_glds_body<BM, BN, NST, NT>(P, bx, by, bz, gridDim.x / P.tiles_m, gridDim.x * gridDim.y * gridDim.z, smem);
 }
 
-template <int BM, int BN, int NST>
+template <int BM, int BN, int NST, int NT = 1>
 __global__ __launch_bounds__(256) void wgrad_glds_jobs_kernel(const GemmParams* __restrict__ jobs,
                                                               const int* __restrict__ map) {
-  __shared__ __attribute__((aligned(1024))) char smem[NST * BK * (BM + BN) * 2];
+  __shared__ __attribute__((aligned(1024))) char smem[NST * BK * (NT * BM + BN) * 2];
   const GemmParams& P = jobs[map[2 * blockIdx.x]];
   const int lb = map[2 * blockIdx.x + 1];
   const int nx = P.grid[0], ny = P.grid[1];
   const int bx = lb % nx, r = lb / nx;
-  wgrad_glds_body<BM, BN, NST>(P, bx, r % ny, r / ny, nx / P.tiles_m, nx * ny * P.grid[2], smem);
+  wgrad_glds_body<BM, BN, NST, NT>(P, bx, r % ny, r / ny, nx / P.tiles_m, nx * ny * P.grid[2], smem);
 }
 
 // Tile of the convolution kernel for a problem: Cout x pixels per phase.  Small problems take 64-pixel tiles
@@ -2581,9 +2604,29 @@ extern "C" int ried_conv2d_bn(const void* x, long long ldx, const void* w, void*
                      stats, 0, 0, nullptr, 0, nullptr, 0, 0.f, 0, &f, stream);
 }
 
+// Taps per block of the weight-gradient kernel (wgrad_glds_body's NT), for layers with at most 64 gathered channels.  ried_conv2d_wgrad_row_blocks(0) turns that off for later calls (A/B runs, tests); plans
+// built before keep the split counts and job tables they were built with.
+static int g_wgrad_rows = 1;
+extern "C" int ried_conv2d_wgrad_row_blocks(int on) { g_wgrad_rows = on != 0; return RIED_OK; }
+// (Measured, 3 x 3 layers at 256 / 128 images: 64 -> 128 channels stride 2 on 64 x 64 maps 86 -> 63 us, 64 -> 64 stride
+// 1 on 64 x 64 maps 102 -> 64 us; 48 -> 48 on 16 x 16 and 32 -> 64 stride 2 on 32 x 32 maps 11 -> 16 us: with few
+// pixels the kernel row's three-fold work per block leaves too few blocks.  Hence the rule below.)
+// The rule: a 3 x 3 layer's kernel row (3 taps) or half a 4 x 4 layer's (2 taps) per block when, at the 384 blocks a
+// launch wants, every block still walks at least 1024 pixels.
+static int wgrad_taps_per_block(int Cg, int Cp, int kh, int kw, long long npix) {
+  if (Cg > 64 || !g_wgrad_rows || g_forced_tile[0] == -3) return 1;
+  const int nt = (kh == 3 && kw == 3) ? 3 : (kh == 4 && kw == 4) ? 2 : 1;
+  if (nt == 1) return 1;
+  const long long per_split = (long long)ceil_div(Cp, Cp <= 64 ? 64 : 128) * (kh * kw / nt);
+  return npix * per_split >= 384ll * 1024 ? nt : 1;
+}
+extern "C" int ried_conv2d_wgrad_taps_per_block(int Cg, int Cp, int kh, int kw, long long npix) {
+  return wgrad_taps_per_block(Cg, Cp, kh, kw, npix);
+}
+
 static int wgrad_params(GemmParams& P, const void* g, long long ldg, int Cg, int nimg, int H, int W, const void* p,
                         long long ldp, int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw,
-                        float* slab, int splitk, int& bm, int& bn) {
+                        float* slab, int splitk, int& bm, int& bn, int& nt) {
   RIED_CHECK_ARG(g && p && slab, "ried_conv2d_wgrad: null pointer");
   RIED_CHECK_ARG(Cg % 8 == 0 && Cp % 8 == 0 && ldg % 8 == 0 && ldp % 8 == 0, "ried_conv2d_wgrad: channels %% 8");
   RIED_CHECK_ARG(((uintptr_t)g % 16) == 0 && ((uintptr_t)p % 16) == 0 && ((uintptr_t)slab % 16) == 0,
@@ -2604,8 +2647,9 @@ static int wgrad_params(GemmParams& P, const void* g, long long ldg, int Cg, int
   P.E.tap_stride = (long long)Cp * Cg;
   P.E.batch_stride = (long long)kh * kw * Cp * Cg;      // per split
   bm = Cg <= 64 ? 64 : 128; bn = Cp <= 64 ? 64 : 128;    // ried_conv2d_wgrad_tiles mirrors this
+  nt = wgrad_taps_per_block(Cg, Cp, kh, kw, npix);
   P.tiles_m = ceil_div(Cg, bm);
-  P.grid[0] = P.tiles_m * ceil_div(Cp, bn); P.grid[1] = kh * kw; P.grid[2] = splitk;
+  P.grid[0] = P.tiles_m * ceil_div(Cp, bn); P.grid[1] = kh * kw / nt; P.grid[2] = splitk;
   const long long a_bytes = (((long long)nimg * H * W - 1) * ldg + Cg) * 2, b_bytes = ((npix - 1) * ldp + Cp) * 2;
   RIED_CHECK_ARG(a_bytes < (long long)GLDS_OOB && b_bytes < (long long)GLDS_OOB, "ried_conv2d_wgrad: operand larger than 4 GiB");
   P.A_bytes = (unsigned)a_bytes; P.B_bytes = (unsigned)b_bytes;
@@ -2634,11 +2678,17 @@ extern "C" int ried_conv2d_wgrad(const void* g, long long ldg, int Cg, int nimg,
                                  long long ldp, int Cp, int Ho, int Wo, int kh, int kw, int sh, int sw, int ph, int pw,
                                  float* slab, int splitk, hipStream_t stream) {
   GemmParams P;
-  int bm, bn;
-  int rc = wgrad_params(P, g, ldg, Cg, nimg, H, W, p, ldp, Cp, Ho, Wo, kh, kw, sh, sw, ph, pw, slab, splitk, bm, bn);
+  int bm, bn, nt;
+  int rc = wgrad_params(P, g, ldg, Cg, nimg, H, W, p, ldp, Cp, Ho, Wo, kh, kw, sh, sw, ph, pw, slab, splitk, bm, bn, nt);
   if (rc) return rc;
   dim3 grid(P.grid[0], P.grid[1], P.grid[2]);
-  if (g_forced_tile[0] == -3) {              // tuning hook: the register-staged form
+  if (nt == 3) {                             // a kernel row per block (bm = 64)
+    if (bn == 64) hipLaunchKernelGGL((wgrad_glds_kernel<64, 64, 2, 3>), grid, dim3(256), 0, stream, P);
+    else hipLaunchKernelGGL((wgrad_glds_kernel<64, 128, 2, 3>), grid, dim3(256), 0, stream, P);
+  } else if (nt == 2) {
+    if (bn == 64) hipLaunchKernelGGL((wgrad_glds_kernel<64, 64, 2, 2>), grid, dim3(256), 0, stream, P);
+    else hipLaunchKernelGGL((wgrad_glds_kernel<64, 128, 2, 2>), grid, dim3(256), 0, stream, P);
+  } else if (g_forced_tile[0] == -3) {       // tuning hook: the register-staged form
     if (bm == 64 && bn == 64) launch<64, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
     else if (bm == 64) launch<64, 128, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
     else if (bn == 64) launch<128, 64, OP_GATHER_TR, OP_PLAIN_TR>(P, grid, stream);
@@ -2665,9 +2715,11 @@ extern "C" int ried_conv2d_wgrad_make_job(void* job_host, const void* g, long lo
                                           int sw, int ph, int pw, float* slab, int splitk, int* tile, int* nblocks) {
   RIED_CHECK_ARG(job_host && tile && nblocks, "ried_conv2d_wgrad_make_job: null pointer");
   GemmParams P;
+  int nt;
   int rc = wgrad_params(P, g, ldg, Cg, nimg, H, W, p, ldp, Cp, Ho, Wo, kh, kw, sh, sw, ph, pw, slab, splitk, tile[0],
-                        tile[1]);
+                        tile[1], nt);
   if (rc) return rc;
+  tile[1] |= (nt - 1) << 16;        // jobs of one launch share the taps per block too: part of the tile key
   memcpy(job_host, &P, sizeof(P));
   *nblocks = P.grid[0] * P.grid[1] * P.grid[2];
   return RIED_OK;
@@ -2677,6 +2729,17 @@ extern "C" int ried_conv2d_wgrad_jobs(const void* jobs, const int* map, int nblo
                                       hipStream_t stream) {
   RIED_CHECK_ARG(jobs && map && nblocks > 0, "ried_conv2d_wgrad_jobs: bad arguments");
   const GemmParams* J = (const GemmParams*)jobs;
+  const int nt = (bn >> 16) + 1;          // taps per block of these jobs (ried_conv2d_wgrad_make_job's tile key)
+  bn &= 0xFFFF;
+  if (nt > 1 && nt <= 3 && bm == 64 && (bn == 64 || bn == 128)) {
+    if (nt == 3 && bn == 64) hipLaunchKernelGGL((wgrad_glds_jobs_kernel<64, 64, 2, 3>), dim3(nblocks), dim3(256), 0, stream, J, map);
+    else if (nt == 3) hipLaunchKernelGGL((wgrad_glds_jobs_kernel<64, 128, 2, 3>), dim3(nblocks), dim3(256), 0, stream, J, map);
+    else if (bn == 64) hipLaunchKernelGGL((wgrad_glds_jobs_kernel<64, 64, 2, 2>), dim3(nblocks), dim3(256), 0, stream, J, map);
+    else hipLaunchKernelGGL((wgrad_glds_jobs_kernel<64, 128, 2, 2>), dim3(nblocks), dim3(256), 0, stream, J, map);
+    RIED_CHECK_LAUNCH("ried_conv2d_wgrad_jobs");
+    return RIED_OK;
+  }
+  RIED_CHECK_ARG(nt == 1, "ried_conv2d_wgrad_jobs: no kernel for %d taps per block at tile %dx%d", nt, bm, bn);
 #define RIED_WJ(BM_, BN_)                                                                                  \
   if (bm == BM_ && bn == BN_) {                                                                            \
     if (g_forced_tile[0] == -3)                                                                            \

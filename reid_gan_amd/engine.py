@@ -436,8 +436,8 @@ class ConvCore:
             # weight gradient: gathered tensor g / pixel-indexed tensor p (see ried_conv2d_wgrad)
             cg, cp = (cout, cin) if deconv else (cin, cout)
             kp = N * (H * W if deconv else self.Ho * self.Wo)
-            self.splitk = _splitk(ops.conv2d_wgrad_tiles(cg, cp) * taps, kp, ctx.splitk_target, ctx.splitk_minpix,
-                                  whole_rounds=ctx.splitk_whole_rounds)
+            self.splitk = _splitk(ops.conv2d_wgrad_blocks(cg, cp, self.kh, self.kw, kp), kp, ctx.splitk_target,
+                                  ctx.splitk_minpix, whole_rounds=ctx.splitk_whole_rounds)
             self.slab_off = ctx.alloc_slab(self.splitk * taps * cin * cout)
             out = ctx.st.g[wname] if wgrad_out is None else wgrad_out
             if pool_fold: # slab [splitk][9][Cp=cout][Cg=cin]: (split, tap) is one reduction axis -> master (Cout,Cin,1,1)
@@ -895,6 +895,8 @@ def bn_jobs_mode(layers, npix: int, maxc: int) -> int:
     return 2 if BN_BWD_ONE and ops.bn_backward_fused_ok(npix, maxc, len(layers)) else 1
 
 
+if os.environ.get("RIED_NO_WGRAD_ROWS"):      # A/B switch: every weight gradient one tap per block
+    ops.lib.ried_conv2d_wgrad_row_blocks(0)
 SIBLING_GROUPS = not os.environ.get("RIED_NO_SIBLING_GROUPS")      # switch for A/B runs and tests
 FUSED_ATTN = not os.environ.get("RIED_NO_FUSED_ATTN")
 PACK_TILES = not os.environ.get("RIED_NO_PACK_TILES")

@@ -185,8 +185,9 @@ class WgradJobs:
         tile, nb = np.zeros(2, dtype=np.int32), np.zeros(1, dtype=np.int32)
         lib.ried_conv2d_wgrad_make_job(rec.ctypes.data, g.ptr, g.ld, g.C, g.N, g.H, g.W, p.ptr, p.ld, p.C, p.H, p.W,
                                        kh, kw, sh, sw, ph, pw, slab_ptr, splitk, tile.ctypes.data, nb.ctypes.data)
+        # (tile[1] carries the taps per block above bit 16: jobs of one launch must agree on that too)
         recs, counts = self.groups.setdefault((int(tile[0]), int(tile[1])), ([], []))
-        recs.append(rec); counts.append((int(nb[0]), kh * kw * (int(nb[0]) // (kh * kw * splitk))))
+        recs.append(rec); counts.append((int(nb[0]), int(nb[0]) // splitk))       # (blocks, blocks per k split)
         self.flops += 2.0 * p.npix * p.C * g.C * kh * kw
         key = (int(tile[0]), int(tile[1]))
         self.group_flops[key] = self.group_flops.get(key, 0.0) + 2.0 * p.npix * p.C * g.C * kh * kw
@@ -277,6 +278,11 @@ class ConvJobs:
 
 def conv2d_wgrad_tiles(Cg, Cp) -> int:
     return lib.ried_conv2d_wgrad_tiles(Cg, Cp)
+
+
+def conv2d_wgrad_blocks(Cg, Cp, kh, kw, npix) -> int:
+    """Blocks per k split of conv2d_wgrad over npix output pixels: tiles x taps / the taps one block computes."""
+    return lib.ried_conv2d_wgrad_tiles(Cg, Cp) * (kh * kw // lib.ried_conv2d_wgrad_taps_per_block(Cg, Cp, kh, kw, npix))
 
 
 def wgrad_reduce(slab, splitk, taps, Cp, Cg, out: torch.Tensor, st, sp, sg, scale=1.0, accumulate=False):

@@ -406,6 +406,12 @@ def test_conv2d_transposed(cin, cout, k, s, p, H, op):
 
 WGRAD_CASES = [
     (64, 128, (3, 3), 1, (1, 1), 8, 5),
+    (64, 128, (3, 3), 2, (1, 1), 16, 7),
+    (48, 48, (3, 3), 1, (1, 1), 8, 1),
+    # 3 x 3, at most 64 input channels, enough output pixels: a kernel row per block
+    (24, 40, (3, 3), 1, (1, 1), 224, 5),
+    (64, 136, (3, 3), 2, (1, 1), 384, 37),
+    (8, 64, (3, 3), 2, (1, 1), 450, 3),
     (32, 64, (3, 3), 2, (1, 1), 16, 3),
     (16, 32, (3, 3), 1, (1, 1), 8, 2),
     (256, 64, (1, 1), 1, (0, 0), 8, 4),
@@ -428,11 +434,15 @@ def test_conv2d_wgrad(cin, cout, k, s, p, H, splitk):
     out = torch.zeros(cout, cin, *k, device=DEV)
     ops.wgrad_reduce(slab, splitk, taps, cout, cin, out, 1, cin * taps, taps)
     close(out.cpu(), ref, 3e-3, "dW")
+    if H >= 200:
+        assert lib.ried_conv2d_wgrad_taps_per_block(cin, cout, k[0], k[1], y.shape[0] * y.shape[2] * y.shape[3]) == 3
 
 
-def test_deconv_wgrad():
-    cin, cout, H = 96, 32, 8
-    x = r(2, cin, H, H, seed=11)
+@pytest.mark.parametrize("cin,cout,H,N,nt", [(96, 32, 8, 2, 1), (96, 32, 128, 3, 2), (40, 64, 160, 2, 2)])
+def test_deconv_wgrad(cin, cout, H, N, nt):
+    """nt: taps of the 4 x 4 window per block (two where every block still has enough pixels to walk)."""
+    assert lib.ried_conv2d_wgrad_taps_per_block(cout, cin, 4, 4, N * H * H) == nt
+    x = r(N, cin, H, H, seed=11)
     w = r(cin, cout, 4, 4, seed=12).requires_grad_(True)
     y = F.conv_transpose2d(x, w, None, 2, 1)
     dy = r(*y.shape, seed=13)

@@ -3,16 +3,16 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from reid_gan_amd import ops
-from reid_gan_amd.engine import _splitk
+from reid_gan_amd.engine import _splitk      # (RIED_NO_WGRAD_ROWS=1: one tap per block)
 
 CASES = [(256, 64, 64, 128, 2), (256, 32, 128, 256, 2), (256, 16, 256, 512, 2), (256, 8, 512, 512, 2),
-         (128, 64, 64, 64, 1), (128, 32, 128, 128, 1)]
+         (128, 64, 64, 64, 1), (128, 32, 128, 128, 1), (128, 16, 48, 48, 1), (128, 32, 32, 64, 2)]
 for N, H, Cg, Cp, s in CASES:
     Ho = H // s
     g = ops.new_view(N, H, H, Cg); g.base.normal_()
     p = ops.new_view(N, Ho, Ho, Cp); p.base.normal_()
     kp = N * Ho * Ho
-    sk = int(os.environ.get("SPLITK", "0")) or _splitk(ops.conv2d_wgrad_tiles(Cg, Cp) * 9, kp)
+    sk = int(os.environ.get("SPLITK", "0")) or _splitk(ops.conv2d_wgrad_blocks(Cg, Cp, 3, 3, kp), kp, whole_rounds=True)
     slab = torch.empty(sk * 9 * Cp * Cg, device="cuda")
     f = lambda: ops.conv2d_wgrad(g, p, 3, 3, s, s, 1, 1, slab, sk)
     f(); torch.cuda.synchronize()
