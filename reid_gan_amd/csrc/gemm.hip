@@ -1823,19 +1823,24 @@ __device__ constexpr D4Step D4_STEPS[16] = {
     {2, 3, 1, -1},                                                       // shift ( 1, -1)
     {3, 0, 1, 1}};                                                       // shift ( 1,  1)
 
-template <int BM>
-__global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P) {
+// TSY = 8 (BM = 32): tiles of 8 x 16 input positions.  Half the accumulators and half the input tile: 80 KB of LDS and
+// under 128 registers, so two blocks share a CU and one's four epilogues run under the other's main loop (the layer
+// with 32 output channels moves 0.9 GB at 512 x 512 output and was bound by neither pipe nor memory: one block per
+// CU, half of its time in the epilogues).
+template <int BM, int TSY = 16>
+__global__ __launch_bounds__(512, TSY == 8 ? 4 : 2) void conv_halo_d4_kernel(const GemmParams P) {
   // BM = 32: a weight stage (64 rows) holds the taps of TWO consecutive products, rows 0-31 and 32-63, and a step runs
   // both between one pair of barriers: 16 MFMAs per wave and barrier instead of 8 (the layer with 32 output channels
   // was bound by its barriers), eight steps per slab.
   constexpr int PAIR = BM == 32 ? 2 : 1;
-  constexpr int TS = 16, BN = 256, WN = 4, NSTEP = 16 / PAIR;
-  constexpr int TWP = TS + 2, HR = TWP * TWP;              // 324 input pixels per block
-  constexpr int NLB = (HR * 8 + 511) / 512;                // 6
+  constexpr int TS = 16, BN = TSY * TS, WN = 4, NSTEP = 16 / PAIR;
+  constexpr int TWP = TS + 2, HR = (TSY + 2) * TWP;        // 324 (180) input pixels per block
+  constexpr int NLB = (HR * 8 + 511) / 512;                // 6 (3)
   constexpr int BBUF = NLB * 512 * 16;
   constexpr int NLA = 1, ABUF = 64 * 128, NSA = 4;         // weight ring: 4 stages of 64 rows x 64 channels
-  constexpr int TM = BM / 32, TN = 4;
+  constexpr int TM = BM / 32, TN = BN / 64;
   static_assert(BM == 32 || BM == 64, "output-channel tile");
+  static_assert(TSY == 16 || TSY == 8, "tile height");
   constexpr unsigned A_OOB = 0xFFFF0000u, B_OOB = 0xFFFFF000u;
   __shared__ __attribute__((aligned(1024))) char smem[NSA * ABUF + 2 * BBUF];
   char* const sA = smem;
@@ -1855,9 +1860,9 @@ __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P
   }
   const int tm = bid % P.tiles_m, tn = bid / P.tiles_m;
   const int m0 = tm * BM;
-  const int tX = X.W / TS, tY = X.H / TS;
+  const int tX = X.W / TS, tY = X.H / TSY;
   const int img0 = tn / (tX * tY), trem = tn % (tX * tY);
-  const int ty0 = (trem / tX) * TS, tx0 = (trem % tX) * TS;
+  const int ty0 = (trem / tX) * TSY, tx0 = (trem % tX) * TS;
   const int nsl = (P.K + 63) >> 6;
   const bool half_tail = (P.K & 63) != 0;                  // Cin % 64 == 32
 
@@ -1907,7 +1912,7 @@ __global__ __launch_bounds__(512, 2) void conv_halo_d4_kernel(const GemmParams P
   int hr0[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int p = wn * 64 + j * 16 + (lane & 15);
+    const int p = wn * (BN / 4) + j * 16 + (lane & 15);
     hr0[j] = (p / TS + 1) * TWP + (p % TS) + 1;
   }
   bf16x8_t fa[2][TM], fb[2][TN];
@@ -2431,14 +2436,18 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
       // (ried_conv2d_force_tile(0, 1, 0) lifts this rule: tests reach the kernel with small inputs)
       ((long long)nimg * (H / 16) * (W / 16) * ceil_div(Cout, Cout <= 32 ? 32 : 64) >= 256 || g_forced_tile[1] == 1)) {
     const int bm = Cout <= 32 ? 32 : 64;
+    // (tuning hooks: nst = 4: 16 x 16 tiles always; nst = 5: 8 x 16 tiles for 64 output channels too)
+    const int tsy = ((bm == 32 || g_forced_tile[2] == 5) && g_forced_tile[2] != 4) ? 8 : 16;
     P.tiles_m = ceil_div(Cout, bm);
-    const int ntiles = nimg * (H / 16) * (W / 16);
-    if (img_stats) P.E.stats_img_tiles = (H / 16) * (W / 16);
-    else if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * 256 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
+    const int ntiles = nimg * (H / tsy) * (W / 16);
+    if (img_stats) P.E.stats_img_tiles = (H / tsy) * (W / 16);
+    else if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * tsy * 16 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
     const dim3 hgrid(P.tiles_m * ntiles);
-    if (which) { which[0] = 3; which[1] = bm; which[2] = 16; which[3] = 0; return RIED_OK; }
-    if (bm == 32) hipLaunchKernelGGL(conv_halo_d4_kernel<32>, hgrid, dim3(512), 0, stream, P);
-    else hipLaunchKernelGGL(conv_halo_d4_kernel<64>, hgrid, dim3(512), 0, stream, P);
+    if (which) { which[0] = 3; which[1] = bm; which[2] = tsy; which[3] = 0; return RIED_OK; }
+    if (bm == 32 && tsy == 8) hipLaunchKernelGGL((conv_halo_d4_kernel<32, 8>), hgrid, dim3(512), 0, stream, P);
+    else if (bm == 32) hipLaunchKernelGGL((conv_halo_d4_kernel<32, 16>), hgrid, dim3(512), 0, stream, P);
+    else if (tsy == 8) hipLaunchKernelGGL((conv_halo_d4_kernel<64, 8>), hgrid, dim3(512), 0, stream, P);
+    else hipLaunchKernelGGL((conv_halo_d4_kernel<64, 16>), hgrid, dim3(512), 0, stream, P);
     RIED_CHECK_LAUNCH("ried_conv2d");
     return RIED_OK;
   }
