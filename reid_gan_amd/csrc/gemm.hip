@@ -1827,7 +1827,13 @@ __device__ constexpr D4Step D4_STEPS[16] = {
 // under 128 registers, so two blocks share a CU and one's four epilogues run under the other's main loop (the layer
 // with 32 output channels moves 0.9 GB at 512 x 512 output and was bound by neither pipe nor memory: one block per
 // CU, half of its time in the epilogues).
-template <int BM, int TSY = 16>
+// XF (input transform, GemmParams::xf_*): the input is the RAW output of the producing layer(s) and each 64-channel
+// slab of the tile is normalised in place in LDS - x -> relu(x * scale[c] + shift[c]), pixels outside the map stay zero
+// - once, before its sixteen products read it (the tile serves all taps, so the transform is paid once per element, not
+// once per tap as in the general kernel).  The per-channel scale and shift sit in a thread's registers from the start
+// of the kernel and reach the slab's threads through the slack behind the OTHER tile buffer (the lane-linear DMA
+// destination is longer than the tile), which no load touches between the write and the read.
+template <int BM, int TSY = 16, bool XF = false>
 __global__ __launch_bounds__(512, TSY == 8 ? 4 : 2) void conv_halo_d4_kernel(const GemmParams P) {
   // BM = 32: a weight stage (64 rows) holds the taps of TWO consecutive products, rows 0-31 and 32-63, and a step runs
   // both between one pair of barriers: 16 MFMAs per wave and barrier instead of 8 (the layer with 32 output channels
@@ -1873,7 +1879,8 @@ __global__ __launch_bounds__(512, TSY == 8 ? 4 : 2) void conv_halo_d4_kernel(con
     const int mr = PAIR == 2 ? (m & 31) : m;               // (paired stages: rows 32-63 are the second tap's rows 0-31)
     aoff[i] = m0 + mr < P.M ? (unsigned)(m0 + mr) * (unsigned)P.A.ld * 2u + (unsigned)q * 16u : A_OOB;
   }
-  const bool second_tap = PAIR == 2 && ((tid >> 3) & 32);  // this lane's weight row belongs to the step's second tap
+  int second_tap_i = (PAIR == 2 && ((tid >> 3) & 32)) ? 1 : 0;   // this lane's weight row belongs to the step's second tap
+  asm volatile("" : "+v"(second_tap_i));
 #pragma unroll
   for (int i = 0; i < NLB; ++i) {
     const int ci = i * 512 + tid, hr = ci >> 3, q = (ci & 7) ^ (hr & 7);
@@ -1884,11 +1891,56 @@ __global__ __launch_bounds__(512, TSY == 8 ? 4 : 2) void conv_halo_d4_kernel(con
   }
   char* const dA = sA + wave * 1024;
   char* const dB = sB + wave * 1024;
+  // XF: this thread's channel (Cin <= 512, host-checked) and the validity of the pixels its chunks belong to
+  static_assert(!XF || BBUF - HR * 128 >= 512, "room for a slab's scale / shift table behind the tile");
+  float xsc = 0.f, xsh = 0.f;
+  unsigned xok = 0u;
+  if constexpr (XF) {
+    if (tid < P.K) {
+      const float a = P.xf_gamma[tid] * P.xf_save[P.K + tid];
+      xsc = a; xsh = P.xf_beta[tid] - P.xf_save[tid] * a;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int hr = (i * 512 + tid) >> 3, hy = hr / TWP, hx = hr - hy * TWP;
+      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+      if (hr < HR && (unsigned)iy < (unsigned)X.H && (unsigned)ix < (unsigned)X.W) xok |= 1u << i;
+    }
+  }
+  // table of slab s: [scale 64 | shift 64] floats behind tile buffer (s + 1) & 1, written by threads 64 s .. 64 s + 63
+  auto xf_table = [&](int slab) { return reinterpret_cast<float*>(sB + ((slab + 1) & 1) * BBUF + HR * 128); };
+  auto xf_publish = [&](int slab) {
+    if ((tid >> 6) == slab) { float* t = xf_table(slab); t[tid & 63] = xsc; t[64 + (tid & 63)] = xsh; }
+  };
+  auto xf_apply = [&](int slab) {
+    const float* tab = xf_table(slab);
+    char* tile = sB + (slab & 1) * BBUF;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+      const int ci = i * 512 + tid, hr = ci >> 3, q = (ci & 7) ^ (hr & 7);
+      if (!((xok >> i) & 1u) || slab * 64 + q * 8 >= P.K) continue;
+      u32x4* p = reinterpret_cast<u32x4*>(tile + ci * 16);
+      const u32x4 v = *p;
+      const f32x4 s0 = *reinterpret_cast<const f32x4*>(tab + q * 8), s1 = *reinterpret_cast<const f32x4*>(tab + q * 8 + 4);
+      const f32x4 h0 = *reinterpret_cast<const f32x4*>(tab + 64 + q * 8), h1 = *reinterpret_cast<const f32x4*>(tab + 64 + q * 8 + 4);
+      float f[8] = {bflo(v[0]), bfhi(v[0]), bflo(v[1]), bfhi(v[1]), bflo(v[2]), bfhi(v[2]), bflo(v[3]), bfhi(v[3])};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { f[e] = f[e] * s0[e] + h0[e]; f[4 + e] = f[4 + e] * s1[e] + h1[e]; }
+      if (P.xf_act == 1) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+      }
+      *p = u32x4{pack2bf(f[0], f[1]), pack2bf(f[2], f[3]), pack2bf(f[4], f[5]), pack2bf(f[6], f[7])};
+    }
+  };
   auto issueA = [&](int slab, int step, int stage) {
     unsigned dead = slab < nsl ? 0u : A_OOB;
     asm volatile("" : "+v"(dead));
-    unsigned wk = (unsigned)(D4_STEPS[step * PAIR].wtap * P.K + slab * 64) * 2u;
-    if (PAIR == 2 && second_tap) wk = (unsigned)(D4_STEPS[step * PAIR + PAIR - 1].wtap * P.K + slab * 64) * 2u;
+    // (the second tap's rows: tap A + (tap B - tap A) * 1, in arithmetic - written as a choice between two table
+    // entries the compiler loads the entry from memory through a per-lane index and waits for vmcnt(0), which drains
+    // every weight DMA in flight, at every step)
+    const int wta = D4_STEPS[step * PAIR].wtap, wtd = D4_STEPS[step * PAIR + PAIR - 1].wtap - wta;
+    const unsigned wk = (unsigned)((wta + wtd * second_tap_i) * P.K + slab * 64) * 2u;
 #pragma unroll
     for (int i = 0; i < NLA; ++i) glds16(rsA, (aoff[i] + wk) | dead, dA + stage * ABUF + i * 8192);
   };
@@ -1937,6 +1989,7 @@ __global__ __launch_bounds__(512, TSY == 8 ? 4 : 2) void conv_halo_d4_kernel(con
   issueA(0, 0, 0);
   issueA(0, 1, 1);
   issueA(0, 2, 2);
+  if constexpr (XF) xf_publish(0);
   for (int slab = 0; slab < nsl; ++slab) {
     const bool both = !(half_tail && slab == nsl - 1);
 #pragma unroll
@@ -1952,6 +2005,14 @@ __global__ __launch_bounds__(512, TSY == 8 ? 4 : 2) void conv_halo_d4_kernel(con
       else if (n_after == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      if constexpr (XF) {
+        if (step == 0) {       // the slab's tile has landed and nobody has read it yet
+          xf_apply(slab);
+          xf_publish(slab + 1);
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (no vmcnt wait: the weight DMAs stay in flight)
+          __builtin_amdgcn_s_barrier();
+        }
+      }
 #pragma unroll
       for (int sub = 0; sub < PAIR; ++sub) {
         const int t = step * PAIR + sub;                       // index into the sixteen (phase, tap) products
@@ -2429,7 +2490,9 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   }
   RIED_CHECK_ARG(!fold, "ried_conv2d_s2_dgrad_c1fold: needs a 3x3 stride-2 layer on maps of whole 16 x 16 tiles");
   // ConvTranspose2d(4, 2, 1) forward on maps of whole 16x16 tiles: all four phases of a tile in one block
-  if (!xf && g_forced_tile[0] == 0 && P.E.staged && transposed && kh == 4 && kw == 4 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
+  // (an input transform only in the 8 x 16-tile form for at most 32 output channels)
+  if ((!xf || (Cout <= 32 && Cin <= 512 && g_forced_tile[2] != 4)) &&
+      g_forced_tile[0] == 0 && P.E.staged && transposed && kh == 4 && kw == 4 && sh == 2 && sw == 2 && ph == 1 && pw == 1 &&
       Ho == 2 * H && Wo == 2 * W && Cin % 32 == 0 && H % 16 == 0 && W % 16 == 0 && a_bytes < 0xFFFF0000ll - 16384 &&
       b_bytes < 0xFFFFF000ll - 1024 &&
       // one block per CU: below a block per CU the general kernel's smaller tiles fill the chip better
@@ -2444,7 +2507,8 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
     else if (stats && !P.E.stats_fold) { P.E.stats_zero = 4 * tsy * 16 / t.bn; P.E.stats_rows = ntiles; }   // one row per tile
     const dim3 hgrid(P.tiles_m * ntiles);
     if (which) { which[0] = 3; which[1] = bm; which[2] = tsy; which[3] = 0; return RIED_OK; }
-    if (bm == 32 && tsy == 8) hipLaunchKernelGGL((conv_halo_d4_kernel<32, 8>), hgrid, dim3(512), 0, stream, P);
+    if (bm == 32 && tsy == 8 && xf) hipLaunchKernelGGL((conv_halo_d4_kernel<32, 8, true>), hgrid, dim3(512), 0, stream, P);
+    else if (bm == 32 && tsy == 8) hipLaunchKernelGGL((conv_halo_d4_kernel<32, 8>), hgrid, dim3(512), 0, stream, P);
     else if (bm == 32) hipLaunchKernelGGL((conv_halo_d4_kernel<32, 16>), hgrid, dim3(512), 0, stream, P);
     else if (tsy == 8) hipLaunchKernelGGL((conv_halo_d4_kernel<64, 8>), hgrid, dim3(512), 0, stream, P);
     else hipLaunchKernelGGL((conv_halo_d4_kernel<64, 16>), hgrid, dim3(512), 0, stream, P);
