@@ -469,6 +469,20 @@ class ConvCore:
 
     def conv(self, y: View, x: Optional[View] = None, **kw):
         src = self.xf_src
+        mix = getattr(self, "xf_mixed", None)
+        if mix is not None and x is None:
+            # The input is a concatenation: channels [c0, c0 + C) hold the RAW output of `layer` (which stopped at its
+            # statistics), the rest finished activations.  One per-channel table - identity for the finished channels
+            # (they are >= 0: the ReLU leaves them alone), the layer's BatchNorm for the raw ones - is refreshed from
+            # the layer's statistics and parameters, and the kernel normalises its operand on the way in.
+            layer, c0, save, gamma, beta = mix
+            st, C = self.ctx.st, layer.core.cout
+            save.view(2, -1)[:, c0:c0 + C].copy_(layer.save.view(2, C))
+            gamma[c0:c0 + C].copy_(st.p[layer.bn + ".weight"])
+            beta[c0:c0 + C].copy_(st.p[layer.bn + ".bias"])
+            ops.conv2d_xf(self.xin.v, self.wp, y, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, save, gamma,
+                          beta, layer.act, transposed=self.deconv, **kw)
+            return
         if src is not None and x is None:    # the producer stopped at its statistics: normalise its raw output on the fly
             st = self.ctx.st
             ops.conv2d_xf(src.raw, self.wp, y, self.kh, self.kw, self.sh, self.sw, self.ph, self.pw, src.save,
@@ -518,7 +532,7 @@ class ConvBN:
     def __init__(self, ctx: Ctx, prefix: str, cin, cout, k, stride, pad, xin: Slot, out: Slot, deconv=False,
                  accumulate=False, need_dx=True, conv_key=None, bn_key=None, bias=False, act=1, shared=False,
                  wgrad_out: Optional[torch.Tensor] = None, defer_apply=False, pool_fold=False,
-                 xf_src: Optional["ConvBN"] = None, post_pool=False):
+                 xf_src: Optional["ConvBN"] = None, post_pool=False, raw_view: Optional[View] = None):
         """bias / act / shared / wgrad_out serve the legacy networks (src/networks.py:466-542): a conv bias in front
         of the BatchNorm (train mode: it only shifts running_mean), the activation code of ops.bn_apply, layers
         applied several times per forward (BatchNorm and bias gradients then add onto the state's), and a
@@ -528,7 +542,9 @@ class ConvBN:
         post_pool (forward-only plans): the layer is the 1x1 convolution of a branch_pool (src/rinet.py:234,250-251 and
         alike) whose avg_pool2d(3, 1, 1) is applied to the convolution's OUTPUT instead of its input - the two are
         linear and commute (no bias; zero padding) - so the pool runs on cout instead of cin channels and the
-        convolution can ride in the block's sibling group: conv -> pool + statistics (ops.avgpool3_stats) -> BN."""
+        convolution can ride in the block's sibling group: conv -> pool + statistics (ops.avgpool3_stats) -> BN.
+        raw_view (defer_apply layers): where the raw convolution output goes instead of a buffer of the layer's own -
+        the channel slice of a concatenation whose one consumer normalises it on the fly (ConvCore.xf_mixed)."""
         self.ctx, self.prefix, self.lane = ctx, prefix, ctx.build_lane
         conv_key = conv_key or (prefix + (".deconv" if deconv else ".conv"))
         self.bn = bn_key or (prefix + ".bn")
@@ -545,7 +561,8 @@ class ConvBN:
         assert xf_src is None or (not ctx.grads and xf_src.defer_apply and xf_src.core.cout == cin)
         assert out.shape == (c.N, c.Ho, c.Wo, cout), (prefix, out.shape, (c.N, c.Ho, c.Wo, cout))
         self.out, self.accumulate = out, accumulate
-        self.raw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device)
+        assert raw_view is None or (defer_apply and (raw_view.N, raw_view.H, raw_view.W, raw_view.C) == (c.N, c.Ho, c.Wo, cout))
+        self.raw = ops.new_view(c.N, c.Ho, c.Wo, cout, ctx.device) if raw_view is None else raw_view
         self.save = torch.empty(2 * cout, dtype=F32, device=ctx.device)
         self.stat_rows = ops.conv2d_stat_rows(c.N, c.Ho, c.Wo, cin, c.cout, c.kh, c.kw, c.sh, c.sw, deconv)
         self.defer_apply = defer_apply
@@ -1273,6 +1290,8 @@ SIGN_MASK = os.environ.get("RIED_SIGN_MASK", "1") != "0"
 # A discriminator backward pass that wants parameter gradients only forms the first layer's weight gradient inside the
 # second layer's data-gradient kernel and never stores the gradient of the first activation (RIED_C1_FOLD=0: off).
 C1_FOLD = os.environ.get("RIED_C1_FOLD", "1") != "0"
+# Forward-only plans: deconv2 normalises deconv1's raw output inside the deconvolution halo kernel (RIED_NO_D4_XF=1: off).
+D4_XF = not os.environ.get("RIED_NO_D4_XF")
 XF_FUSE_MODE = os.environ.get("RIED_XF_FUSE", "s2")
 XF_FUSE = XF_FUSE_MODE not in ("", "0")
 
@@ -1531,11 +1550,22 @@ class Generator:
         a7 = Slot(ctx.act(N, h8, w8, 256)); body.add(inception_c(ctx, "layer_block_4.0", a6, a7, 512, 64, True))
         a8 = Slot(ctx.act(N, h4, w4, 256)); body.add(inception_b(ctx, "expand_grid_2", a7, a8, 256, True))
         body.add(inception_a(ctx, "layer_block_5.0", a8, self.cat1.sub(64, 192), 256, True))
-        body.add(ConvBN(ctx, "deconv1", 192, 64, 4, 2, 1, self.cat1, self.cat2.sub(32, 96), deconv=True))
+        # Forward-only plans with batch statistics: deconv1 stops at its statistics and leaves its RAW output in its
+        # slice of cat2; deconv2 - its one consumer, on the halo kernel whose input tile serves all sixteen taps -
+        # normalises those 64 channels as it loads them (ConvCore.xf_mixed): the pass that read and rewrote the
+        # 64-channel half-resolution tensor (126 us of a 4.9 ms batch of 32 slices of 512 x 512) is gone.
+        d1_raw = (XF_FUSE and D4_XF and not grads and training and not ctx.per_image and ctx.st is not None
+                  and h2 % 16 == 0 and w2 % 16 == 0)
+        d1 = body.add(ConvBN(ctx, "deconv1", 192, 64, 4, 2, 1, self.cat1, self.cat2.sub(32, 96), deconv=True,
+                             defer_apply=d1_raw, raw_view=self.cat2.sub(32, 96).v if d1_raw else None))
         self.hlast = Slot(ctx.act(N, H, W, 32))
         # forward-only plans: out_conv reads deconv2's raw output and normalises on the fly (hlast stays unwritten)
         self.last = body.add(ConvBN(ctx, "deconv2", 96, 32, 4, 2, 1, self.cat2, self.hlast, deconv=True,
                                     defer_apply=not grads))
+        if d1_raw:
+            ident = torch.cat([torch.zeros(96), torch.ones(96)]).to(device=device, dtype=F32)     # mean 0, invstd 1
+            self.last.core.xf_mixed = (d1, 32, ident, torch.ones(96, dtype=F32, device=device),
+                                       torch.zeros(96, dtype=F32, device=device))
         self.body = body
         self.tops = {"conv1": self.cat2.sub(0, 32), "conv2": c2, "layer_block_1": a1, "reduce_grid_1": a2,
                      "layer_block_2": a3, "reduce_grid_2": a4, "layer_block_3": a5, "expand_grid_1": a6,

@@ -121,6 +121,8 @@ def test_inference_with_the_fused_input_transform(monkeypatch):
         e = InferenceEngine(sd, B, H, H)
         n = len([l for m in e.G.body.layers for l in _walk(m)
                  if isinstance(l, engine.ConvBN) and l.core.xf_src is not None])
+        # deconv2 normalises deconv1's raw output (its slice of the concatenation) inside the deconvolution halo kernel
+        assert (getattr(e.G.last.core, "xf_mixed", None) is not None) == (mode != "0")
         p, s_ = e.run(xd, yd)
         return n, p.cpu().clone(), e.measures(s_)
 
@@ -133,6 +135,22 @@ def test_inference_with_the_fused_input_transform(monkeypatch):
         for i in range(B):
             for u, v in zip(m[i][1], ma[i][1]):
                 assert abs(u - v) <= 1e-2 * abs(v) + 1e-5, (what, i, m[i], ma[i])
+
+
+@pytest.mark.parametrize("B,H", [(1, 128), (2, 256)])
+def test_deconv2_normalising_deconv1_in_its_own_kernel(monkeypatch, B, H):
+    """The same switch on its own (engine.D4_XF), where the general kernel takes deconv2 (too few tiles for the halo
+    kernel: one 128 x 128 slice) and where the halo kernel does: same prediction as the plan with the separate pass."""
+    sd = g_state()
+    x, y = synth_batch(B, H, seed=83)
+    outs = []
+    for on in (False, True):
+        monkeypatch.setattr(engine, "D4_XF", on)
+        e = InferenceEngine(sd, B, H, H)
+        assert (getattr(e.G.last.core, "xf_mixed", None) is not None) == on
+        p, _ = e.run(x.to(DEV), y.to(DEV))
+        outs.append(p.cpu().clone())
+    act_close(outs[1], outs[0], "deconv1 normalised inside deconv2 vs separate pass", mx=2e-2, mean=3e-3)
 
 
 def test_training_plan_with_the_pool_branch_folded(monkeypatch):
