@@ -52,7 +52,8 @@ def instrumented_step(ts):
     from reid_gan_amd import ops
     from reid_gan_amd._lib import lib
     rec = []            # (family, template, flops, bytes, event, event)
-    names = ("conv2d", "conv2d_tap_mse", "conv2d_wgrad", "bgemm", "attn_fwd", "attn_bwd")
+    names = ("conv2d", "conv2d_tap_mse", "conv2d_wgrad", "bgemm", "attn_fwd", "attn_bwd", "conv2d_signs",
+             "conv2d_s2_dgrad_c1fold")
     orig = {k: getattr(ops, k) for k in names}
 
     def timed(family, template, flops, nbytes, fn):
@@ -72,6 +73,22 @@ def instrumented_step(ts):
         fl = 2.0 * (x.npix if k.get("transposed") else y.npix) * x.C * y.C * kh * kw_
         timed("conv", ops.conv2d_which(x, w, y, kh, kw_, sh, sw, ph, pw, **k), fl, nb,
               lambda: orig["conv2d"](x, w, y, kh, kw_, sh, sw, ph, pw, **k))
+
+    def conv_signs(x, w, y, kh, kw_, sh, sw, ph, pw, signs, **k):      # the mask is one byte per eight channels
+        nb = 2.0 * (x.npix * x.C + w.numel() + y.npix * y.C) + y.npix * y.C / 8.0
+        fl = 2.0 * (x.npix if k.get("transposed") else y.npix) * x.C * y.C * kh * kw_
+        kk = {a: b for a, b in k.items() if a != "mask_slope"}
+        timed("conv", ops.conv2d_which(x, w, y, kh, kw_, sh, sw, ph, pw, **kk), fl, nb,
+              lambda: orig["conv2d_signs"](x, w, y, kh, kw_, sh, sw, ph, pw, signs, **k))
+
+    def c1fold(dy, wt, mask, mask_slope, stats, ximg, dw, scratch, **k):
+        # data gradient of the 3x3 stride-2 layer into 64 channels at twice the resolution (never stored) + the first
+        # layer's 64 x 9 weight gradient from it; bytes: dy, the weights, the mask, the fp32 image
+        npo = 4.0 * dy.npix
+        mb = npo * 8.0 if not isinstance(mask, ops.View) else 2.0 * npo * 64
+        timed("conv", "conv_halo_s2t_kernel<16,fold>", 2.0 * dy.npix * dy.C * 64 * 9 + 2.0 * npo * 64 * 9,
+              2.0 * (dy.npix * dy.C + wt.numel()) + mb + 4.0 * npo,
+              lambda: orig["conv2d_s2_dgrad_c1fold"](dy, wt, mask, mask_slope, stats, ximg, dw, scratch, **k))
 
     def tap(x, w, bias, y, target, gout, gscale, stats):      # x, w, y, gradient seed (bf16) + the fp32 target tap
         nb = 2.0 * (x.npix * x.C + w.numel() + 2 * y.npix * y.C) + 4.0 * y.npix * y.C
@@ -101,6 +118,7 @@ def instrumented_step(ts):
               2.0 * nimg * n * (4 * d + 4 * C), lambda: orig["attn_bwd"](qkv, dqkv, dout, O, lse_ptr, gamma, dgamma, d))
 
     ops.conv2d, ops.conv2d_tap_mse, ops.conv2d_wgrad, ops.bgemm = conv, tap, wgrad, bgemm
+    ops.conv2d_signs, ops.conv2d_s2_dgrad_c1fold = conv_signs, c1fold
     ops.attn_fwd, ops.attn_bwd = attn_fwd, attn_bwd
     launch_wj, launch_cj = ops.WgradJobs.launch, ops.ConvJobs.launch      # the grouped launches of the generator
 
