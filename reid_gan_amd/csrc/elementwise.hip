@@ -510,6 +510,7 @@ extern "C" int ried_bn_apply_images(const void* x, long long ldx, void* y, long 
 // (block % BN_BWD_FOLD_ROWS) of a zeroed [BN_BWD_FOLD_ROWS][2][C] buffer with float atomics and the apply pass adds
 // the rows up itself, so no launch stands between the two (the sums then depend on the order the blocks finish in).
 #define BN_BWD_FOLD_ROWS 8
+extern "C" int ried_bn_bwd_fold_rows() { return BN_BWD_FOLD_ROWS; }
 // backward pass 1: per-block partial sums[0][c] = sum g, sums[1][c] = sum g*xhat, g = dy * [bn(x) > 0]
 __device__ __forceinline__ void bn_bwd_reduce_body(
     const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx, long long npix, int C,
@@ -698,10 +699,14 @@ __global__ __launch_bounds__(ROWRED_THREADS) void bn_bwd_finish_kernel(const flo
 // Inception block) in three launches instead of three per layer.  A job is 16 64-bit words:
 // dy, lddy, x, ldx, dx, lddx, C, save, gamma, beta, act, scratch, dgamma, dbeta, accumulate, folded
 // (as ried_bn_backward; folded = 0, or the job's zeroed rows of the folded form, and then scratch may be 0).
+// act + BN_JOB_SUMS_PRESENT: the job's folded rows already hold its sums (the data gradient that wrote dy formed them,
+// ried_conv2d_bnbwd): the reduction skips the job.
 #define BN_JOB_WORDS 16
+#define BN_JOB_SUMS_PRESENT 256
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_jobs_kernel(const long long* __restrict__ jobs,
                                                                         long long npix) {
   const long long* J = jobs + (long long)blockIdx.y * BN_JOB_WORDS;
+  if (J[10] & BN_JOB_SUMS_PRESENT) return;
   bn_bwd_reduce_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], npix, (int)J[6], (const float*)J[7],
                      (const float*)J[8], (const float*)J[9], (int)J[10], (float*)J[11], nullptr, nullptr, nullptr,
                      nullptr, 0, (float*)J[15]);
@@ -722,7 +727,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_jobs_kernel(const lon
   float* dg = (J[12] && J[13]) ? (float*)J[12] : nullptr;
   if (J[15])
     bn_bwd_apply_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], (bf16_t*)J[4], J[5], npix, C,
-                      (const float*)J[7], (const float*)J[8], (const float*)J[9], (int)J[10], (const float*)J[15],
+                      (const float*)J[7], (const float*)J[8], (const float*)J[9], (int)J[10] & 255, (const float*)J[15],
                       BN_BWD_FOLD_ROWS, dg, (float*)J[13], (int)J[14]);
   else
     bn_bwd_apply_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], (bf16_t*)J[4], J[5], npix, C,
@@ -918,7 +923,8 @@ extern "C" int ried_bn_backward_jobs(const long long* jobs, int njobs, long long
     return RIED_OK;
   }
   const int grid = chan_grid(npix, maxC, 4, BN_BWD_MAX_ROWS);
-  hipLaunchKernelGGL(bn_bwd_reduce_jobs_kernel, dim3(grid, njobs), dim3(EW_THREADS), 0, stream, jobs, npix);
+  if (all_folded != 3)          // 3: every job's rows hold its sums already (BN_JOB_SUMS_PRESENT) - apply only
+    hipLaunchKernelGGL(bn_bwd_reduce_jobs_kernel, dim3(grid, njobs), dim3(EW_THREADS), 0, stream, jobs, npix);
   if (!all_folded)
     hipLaunchKernelGGL(bn_bwd_finish_jobs_kernel, dim3(ceil_div(maxC, 32), njobs), dim3(ROWRED_THREADS), 0, stream,
                        jobs, grid);
