@@ -148,24 +148,6 @@ int ried_conv2d_make_job(void* job_host, const void* x, long long ldx, const voi
                          int transposed, const float* bias, int act, float* stats, int accumulate, int stats_post,
                          int* nblocks);
 int ried_conv2d_jobs(const void* jobs, const int* map, int nblocks, ried_stream_t stream);
-/* ried_conv2d as the data gradient that PRODUCES the output gradient y of a BasicConv2d / BasicDeconv2d layer
- * (src/rinet.py:183-205; autograd runs cudnn_convolution_backward, then native_batch_norm_backward re-reads the
- * gradient): the epilogue also forms that layer's BatchNorm-backward sums.  bn_x: the layer's raw convolution output
- * (shaped like y, row pitch ld_bn_x); bn_save [2][Cout] its mean and 1/sqrt(var + eps); bn_gamma, bn_beta; bn_act its
- * activation (0 none, 1 ReLU, 2 LeakyReLU 0.2).  folded (zeroed, ried_bn_backward_folded_floats(Cout) floats) +=
- * sum g and sum g * x-hat of the final gradient g (after accumulation) masked by the activation: the input of
- * ried_bn_backward_apply.  y must be bf16 with 16-byte aligned rows.  The _make_job form fills a ried_conv2d_jobs
- * record. */
-int ried_conv2d_bnbwd(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
-                      int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
-                      int accumulate, const void* bn_x, long long ld_bn_x, const float* bn_save, const float* bn_gamma,
-                      const float* bn_beta, int bn_act, float* folded, ried_stream_t stream);
-int ried_conv2d_make_job_bnbwd(void* job_host, const void* x, long long ldx, const void* w, void* y, long long ldy,
-                               int nimg, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw,
-                               int ph, int pw, int transposed, int accumulate, const void* bn_x, long long ld_bn_x,
-                               const float* bn_save, const float* bn_gamma, const float* bn_beta, int bn_act,
-                               float* folded, int* nblocks);
-int ried_bn_bwd_fold_rows(void); /* rows of the folded BatchNorm-backward sums (ried_bn_backward_folded_floats) */
 /* Reporting aid (no counterpart in the reference): which kernel a ried_conv2d call with these arguments runs, without
  * launching it.  which[4] = {kind, bm, bn or tile side, LDS stages}; kind 0 = conv_glds_kernel<bm, bn, stages>,
  * 1 = conv_halo_kernel<bm, side, stages>, 2 = conv_halo_s2t_kernel<side>, 3 = conv_halo_d4_kernel<bm>. */

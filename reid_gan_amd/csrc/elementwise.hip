@@ -7,6 +7,7 @@
 // A tensor "view" is (ptr, ld, C): pixel p's channels are ptr[p*ld .. p*ld+C).
 // Views let producers write straight into channel slices of a concatenation
 // buffer, which removes every torch.cat of src/rinet.py:88-90,245,291,340,387,418-438.
+#include <stdlib.h>
 #include "common.h"
 #include "bn_common.h"
 
@@ -510,7 +511,6 @@ extern "C" int ried_bn_apply_images(const void* x, long long ldx, void* y, long 
 // (block % BN_BWD_FOLD_ROWS) of a zeroed [BN_BWD_FOLD_ROWS][2][C] buffer with float atomics and the apply pass adds
 // the rows up itself, so no launch stands between the two (the sums then depend on the order the blocks finish in).
 #define BN_BWD_FOLD_ROWS 8
-extern "C" int ried_bn_bwd_fold_rows() { return BN_BWD_FOLD_ROWS; }
 // backward pass 1: per-block partial sums[0][c] = sum g, sums[1][c] = sum g*xhat, g = dy * [bn(x) > 0]
 __device__ __forceinline__ void bn_bwd_reduce_body(
     const bf16_t* __restrict__ dy, long long lddy, const bf16_t* __restrict__ x, long long ldx, long long npix, int C,
@@ -699,14 +699,10 @@ __global__ __launch_bounds__(ROWRED_THREADS) void bn_bwd_finish_kernel(const flo
 // Inception block) in three launches instead of three per layer.  A job is 16 64-bit words:
 // dy, lddy, x, ldx, dx, lddx, C, save, gamma, beta, act, scratch, dgamma, dbeta, accumulate, folded
 // (as ried_bn_backward; folded = 0, or the job's zeroed rows of the folded form, and then scratch may be 0).
-// act + BN_JOB_SUMS_PRESENT: the job's folded rows already hold its sums (the data gradient that wrote dy formed them,
-// ried_conv2d_bnbwd): the reduction skips the job.
 #define BN_JOB_WORDS 16
-#define BN_JOB_SUMS_PRESENT 256
 __global__ __launch_bounds__(EW_THREADS) void bn_bwd_reduce_jobs_kernel(const long long* __restrict__ jobs,
                                                                         long long npix) {
   const long long* J = jobs + (long long)blockIdx.y * BN_JOB_WORDS;
-  if (J[10] & BN_JOB_SUMS_PRESENT) return;
   bn_bwd_reduce_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], npix, (int)J[6], (const float*)J[7],
                      (const float*)J[8], (const float*)J[9], (int)J[10], (float*)J[11], nullptr, nullptr, nullptr,
                      nullptr, 0, (float*)J[15]);
@@ -727,7 +723,7 @@ __global__ __launch_bounds__(EW_THREADS) void bn_bwd_apply_jobs_kernel(const lon
   float* dg = (J[12] && J[13]) ? (float*)J[12] : nullptr;
   if (J[15])
     bn_bwd_apply_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], (bf16_t*)J[4], J[5], npix, C,
-                      (const float*)J[7], (const float*)J[8], (const float*)J[9], (int)J[10] & 255, (const float*)J[15],
+                      (const float*)J[7], (const float*)J[8], (const float*)J[9], (int)J[10], (const float*)J[15],
                       BN_BWD_FOLD_ROWS, dg, (float*)J[13], (int)J[14]);
   else
     bn_bwd_apply_body((const bf16_t*)J[0], J[1], (const bf16_t*)J[2], J[3], (bf16_t*)J[4], J[5], npix, C,
@@ -923,8 +919,7 @@ extern "C" int ried_bn_backward_jobs(const long long* jobs, int njobs, long long
     return RIED_OK;
   }
   const int grid = chan_grid(npix, maxC, 4, BN_BWD_MAX_ROWS);
-  if (all_folded != 3)          // 3: every job's rows hold its sums already (BN_JOB_SUMS_PRESENT) - apply only
-    hipLaunchKernelGGL(bn_bwd_reduce_jobs_kernel, dim3(grid, njobs), dim3(EW_THREADS), 0, stream, jobs, npix);
+  hipLaunchKernelGGL(bn_bwd_reduce_jobs_kernel, dim3(grid, njobs), dim3(EW_THREADS), 0, stream, jobs, npix);
   if (!all_folded)
     hipLaunchKernelGGL(bn_bwd_finish_jobs_kernel, dim3(ceil_div(maxC, 32), njobs), dim3(ROWRED_THREADS), 0, stream,
                        jobs, grid);
@@ -1185,10 +1180,28 @@ __global__ __launch_bounds__(EW_THREADS) void bn_apply_train_jobs_kernel(const l
                       (const float*)J[13], (int)J[14], (int)J[15]);
 }
 
-static inline void slice_grid(long long npix, int C, int iters, int cap, dim3& grid) {
+// Pixel groups per block pass x `iters` passes per block.  Every block of these kernels first adds up the folded
+// statistics rows of its channel slice (a fixed cost: 32 rows x 2 x 64 floats and two barriers), so on large layers
+// the blocks take more passes: about `njobs`-th of SLICE_TARGET_BLOCKS blocks in all.
+static int slice_target_blocks() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("RIED_BN_SLICE_BLOCKS");
+    v = e ? atoi(e) : 2048;
+  }
+  return v;
+}
+static inline void slice_grid(long long npix, int C, int iters, int cap, dim3& grid, int njobs = 1) {
   int ccs = C / 8 < BN_SLICE / 8 ? C / 8 : BN_SLICE / 8;
   int ppb = EW_THREADS / ccs;
-  grid = dim3(ew_grid(npix, ppb * iters, cap), ceil_div(C, BN_SLICE));
+  const int gy = ceil_div(C, BN_SLICE);
+  const int target = slice_target_blocks();
+  if (target > 0) {
+    const long long gx = target / (gy * njobs) > 0 ? target / (gy * njobs) : 1;
+    const long long want = (npix + ppb * gx - 1) / (ppb * gx);
+    if (want > iters) iters = (int)(want < 64 ? want : 64);
+  }
+  grid = dim3(ew_grid(npix, ppb * iters, cap), gy);
 }
 
 // stats: [nrows][2][C] folded partial sums (ried_conv2d with stats_post = 2 writes min(BN_FOLD_ROWS, tiles) rows).
@@ -1218,8 +1231,8 @@ extern "C" int ried_bn_apply_train_jobs(const long long* jobs, int njobs, long l
   RIED_CHECK_ARG(jobs && njobs > 0 && njobs <= 65535 && npix > 0 && minC >= 8 && maxC >= minC && maxC % 8 == 0,
                  "ried_bn_apply_train_jobs: bad arguments");
   dim3 grid, g2;
-  slice_grid(npix, maxC, 2, 8192, grid);
-  slice_grid(npix, minC, 2, 8192, g2);          // fewer channels per pixel: fewer pixels per block pass
+  slice_grid(npix, maxC, 2, 8192, grid, njobs);
+  slice_grid(npix, minC, 2, 8192, g2, njobs);          // fewer channels per pixel: fewer pixels per block pass
   grid.x = grid.x > g2.x ? grid.x : g2.x;
   grid.z = njobs;
   hipLaunchKernelGGL(bn_apply_train_jobs_kernel, grid, dim3(EW_THREADS), 0, stream, jobs, npix, eps, momentum);

@@ -66,16 +66,6 @@ struct GemmEpilogue {
   long long ld_gout;
   float gscale;
   int phase_mode, Wo_full, HoWo_full, Hq, Wq, sh, sw;   // logical row -> physical pixel
-  // BatchNorm backward sums of the layer whose OUTPUT gradient this launch writes (staged epilogue only): with x its raw
-  // convolution output (bnx), x-hat = (x - mean) * invstd and g = the final value masked by that layer's activation
-  // (x-hat * gamma + beta > 0), the statistics rows receive sum g and sum g * x-hat (folded: stats_fold rows, float
-  // atomics) - what bn_bwd_reduce would compute in a launch of its own after this one.  The stored value is unchanged.
-  const bf16_t* bnx;       // or null
-  long long ld_bnx;
-  const float* bn_save;    // [2][M] mean, invstd
-  const float* bn_gamma;
-  const float* bn_beta;
-  int bn_act;              // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
   // conv_halo_s2t_kernel<16, true> only: the result (64 channels: the gradient of the first discriminator layer's
   // pre-activation) is not stored; its product with the nine taps of the fp32 image that layer reads - that layer's
   // weight gradient - leaves the block as one row [64][9] of fold_rows
@@ -517,7 +507,7 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 
   float* red = T + BN * LDT;                  // [NW][2][HM] wave totals of the statistics
   const int c = tid % CPR, r0 = tid / CPR;
   bf16_t* outb = (bf16_t*)E.out + (long long)by * E.tap_stride;
-  const bool pre = E.stats && !E.stats_post && !E.sub && !E.bnx;
+  const bool pre = E.stats && !E.stats_post && !E.sub;
 #pragma unroll
   for (int h = 0; h < HALVES; ++h) {
     if (h) __syncthreads();                   // the first half has been read
@@ -542,15 +532,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 
     float s0[8], s1[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) { s0[q] = 0.f; s1[q] = 0.f; }
-    float bmean[8], bistd[8], bgam[8], bbeta[8];      // E.bnx: the thread's eight channels of the layer's BatchNorm
-    if (E.bnx) {
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        bmean[q] = mok ? E.bn_save[m + q] : 0.f; bistd[q] = mok ? E.bn_save[P.M + m + q] : 0.f;
-        bgam[q] = mok ? E.bn_gamma[m + q] : 0.f; bbeta[q] = mok ? E.bn_beta[m + q] : 0.f;
-      }
-    }
-    const float bsl = E.bn_act == 1 ? 0.f : (E.bn_act == 2 ? 0.2f : 1.f);
 #pragma unroll 2
     for (int n = r0; n < BN; n += RPP) {
       float v[8];
@@ -614,16 +595,6 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 
       if (E.stats && E.stats_post) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) { s0[q] += v[q]; s1[q] += v[q] * v[q]; }
-      }
-      if (E.bnx) {
-        const u32x4 xr = *reinterpret_cast<const u32x4*>(E.bnx + orow * E.ld_bnx + m);
-        const float xq[8] = {bflo(xr[0]), bfhi(xr[0]), bflo(xr[1]), bfhi(xr[1]), bflo(xr[2]), bfhi(xr[2]), bflo(xr[3]), bfhi(xr[3])};
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float xh = (xq[q] - bmean[q]) * bistd[q];
-          const float g = v[q] * (xh * bgam[q] + bbeta[q] > 0.f ? 1.f : bsl);
-          s0[q] += g; s1[q] += g * xh;
-        }
       }
       const u32x4 packed = u32x4{pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
       if constexpr (FOLD) *reinterpret_cast<u32x4*>(dt + n * FOLD_DT_PITCH + c * 16) = packed;
@@ -2357,9 +2328,6 @@ struct ConvJobOut { void* rec; int* nblocks; int* which; };
 struct ConvXf { const float* save; const float* gamma; const float* beta; int act; };
 // first-layer weight gradient folded into the stride-2 data gradient (GemmEpilogue::fold_*)
 struct ConvFold { const float* x; float scale, shift; float* rows; };
-// BatchNorm backward sums of the layer whose output gradient the launch writes (GemmEpilogue::bnx ...)
-struct ConvBnBwd { const void* x; long long ldx; const float* save; const float* gamma; const float* beta; int act; };
-extern "C" int ried_bn_bwd_fold_rows();
 
 // Conv2d forward (transposed = 0) or ConvTranspose2d forward / strided-conv data gradient
 // (transposed = 1).  x: NHWC bf16 [nimg][H][W][ldx], channels 0..Cin-1 used.
@@ -2371,7 +2339,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                        int stats_post, const BnFinalize* fin, hipStream_t stream, const float* sub = nullptr,
                        long long ld_sub = 0, void* gout = nullptr, long long ld_gout = 0, float gscale = 0.f,
                        const ConvJobOut* job = nullptr, const ConvXf* xf = nullptr, int mask_bits = 0,
-                       const ConvFold* fold = nullptr, const ConvBnBwd* bnb = nullptr) {
+                       const ConvFold* fold = nullptr) {
   RIED_CHECK_ARG(x && w && (y || fold), "ried_conv2d: null pointer");
   RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
   RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
@@ -2426,16 +2394,6 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   P.E.staged = !fin && !out_f32 && ldy % 8 == 0 && ((uintptr_t)y % 16) == 0 &&
                (!mask || mask_bits || (ldmask % 8 == 0 && ((uintptr_t)mask % 16) == 0)) && (!y2 || ((uintptr_t)y2 % 16) == 0) &&
                (!gout || (ld_gout % 8 == 0 && ((uintptr_t)gout % 16) == 0)) && g_forced_tile[2] != -1;
-  if (bnb) {
-    RIED_CHECK_ARG(bnb->x && bnb->save && bnb->gamma && bnb->beta && stats && !stats_post && !fin && !sub && !xf &&
-                       bnb->ldx % 8 == 0 && bnb->ldx >= Cout && ((uintptr_t)bnb->x % 16) == 0 && bnb->act >= 0 &&
-                       bnb->act <= 2,
-                   "ried_conv2d_bnbwd: bad BatchNorm-backward arguments");
-    RIED_CHECK_ARG(P.E.staged, "ried_conv2d_bnbwd: the output view must be bf16 with 16-byte aligned rows");
-    P.E.bnx = (const bf16_t*)bnb->x; P.E.ld_bnx = bnb->ldx; P.E.bn_save = bnb->save; P.E.bn_gamma = bnb->gamma;
-    P.E.bn_beta = bnb->beta; P.E.bn_act = bnb->act;
-    P.E.stats_fold = ried_bn_bwd_fold_rows();
-  }
   long long a_bytes = (long long)Cout * kh * kw * Cin * 2;
   long long b_bytes = (((long long)nimg * H * W - 1) * ldx + Cin) * 2;
   RIED_CHECK_ARG(a_bytes < (long long)GLDS_OOB - (1 << 28) && b_bytes < (long long)GLDS_OOB,
@@ -2647,37 +2605,6 @@ extern "C" int ried_conv2d_s2_dgrad_c1fold(const void* dy, long long lddy, const
                        nullptr, nullptr, mask_bits, &f);
   if (rc != RIED_OK) return rc;
   return ried_rows_add(scratch, nimg * (H / 16) * (W / 16), 64 * 9, dw, stream);
-}
-
-// ried_conv2d as the data gradient that PRODUCES the output gradient of a BasicConv2d / BasicDeconv2d layer
-// (src/rinet.py:183-205), with that layer's BatchNorm-backward sums formed in the epilogue: bn_x is the layer's raw
-// convolution output (a view shaped like y), bn_save its (mean, 1/sqrt(var + eps)) [2][Cout], bn_gamma / bn_beta its
-// affine parameters, bn_act its activation (0 none, 1 ReLU, 2 LeakyReLU 0.2); `folded` (zeroed by the caller,
-// ried_bn_backward_folded_floats(Cout) floats) receives sum g and sum g * x-hat of the final (accumulated) gradient g
-// masked by the activation - the input of ried_bn_backward_apply, with no reduction launch in between.
-extern "C" int ried_conv2d_bnbwd(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H,
-                                 int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw,
-                                 int transposed, int accumulate, const void* bn_x, long long ld_bn_x,
-                                 const float* bn_save, const float* bn_gamma, const float* bn_beta, int bn_act,
-                                 float* folded, hipStream_t stream) {
-  ConvBnBwd b{bn_x, ld_bn_x, bn_save, bn_gamma, bn_beta, bn_act};
-  return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, nullptr, 0,
-                     folded, accumulate, 0, nullptr, 0, nullptr, 0, 0.f, 0, nullptr, stream, nullptr, 0, nullptr, 0, 0.f,
-                     nullptr, nullptr, 0, nullptr, &b);
-}
-// The job-table form (see ried_conv2d_make_job).
-extern "C" int ried_conv2d_make_job_bnbwd(void* job_host, const void* x, long long ldx, const void* w, void* y,
-                                          long long ldy, int nimg, int H, int W, int Cin, int Ho, int Wo, int Cout, int kh,
-                                          int kw, int sh, int sw, int ph, int pw, int transposed, int accumulate,
-                                          const void* bn_x, long long ld_bn_x, const float* bn_save,
-                                          const float* bn_gamma, const float* bn_beta, int bn_act, float* folded,
-                                          int* nblocks) {
-  RIED_CHECK_ARG(job_host && nblocks, "ried_conv2d_make_job_bnbwd: null pointer");
-  ConvJobOut job{job_host, nblocks, nullptr};
-  ConvBnBwd b{bn_x, ld_bn_x, bn_save, bn_gamma, bn_beta, bn_act};
-  return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, Ho, Wo, Cout, kh, kw, sh, sw, ph, pw, transposed, nullptr, 0,
-                     folded, accumulate, 0, nullptr, 0, nullptr, 0, 0.f, 0, nullptr, nullptr, nullptr, 0, nullptr, 0, 0.f,
-                     &job, nullptr, 0, nullptr, &b);
 }
 
 // ried_conv2d whose input x is the RAW convolution output of a BasicConv2d layer (src/rinet.py:183-205): the kernel

@@ -595,10 +595,6 @@ class ConvBN:
         if fwd_member:
             grp.join(self)
         self.bwd_fold = self.bwd_one = False
-        # feeds: the layer below whose output gradient this layer's data gradient alone writes, and whose BatchNorm
-        # backward sums that launch forms on the way (link_bn_backward); fed: this layer is such a producer
-        self.feeds: Optional["ConvBN"] = None
-        self.fed = False
         if ctx.grads:
             ctx.need_f32(ops.bn_backward_scratch_floats(cout))
             if bias:
@@ -704,11 +700,6 @@ class ConvBN:
             ops.bn_backward_apply(self.out.g, self.raw, self.draw, self.save, gamma, beta, rows,
                                   st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=self.act)
             return
-        if self.fed:       # the consumer's data gradient left the sums in the folded rows
-            ops.bn_backward_apply(self.out.g, self.raw, self.draw, self.save, st.p[self.bn + ".weight"],
-                                  st.p[self.bn + ".bias"], self.bfold[:self.bfold_rows], st.g[self.bn + ".weight"],
-                                  st.g[self.bn + ".bias"], relu=self.act)
-            return
         ops.bn_backward(self.out.g, self.raw, self.draw, self.save, st.p[self.bn + ".weight"], st.p[self.bn + ".bias"],
                         ctx.f32s[self.lane], st.g[self.bn + ".weight"], st.g[self.bn + ".bias"], relu=self.act,
                         accumulate=self.shared, folded=self.bfold if self.bwd_fold else None,
@@ -746,31 +737,22 @@ class ConvBN:
         """The layer's BatchNorm backward as a bn_backward_jobs record (None: a sibling group runs it)."""
         if self.bn_bwd_grouped:
             return None
-        return self.bn_job_record()
-
-    def bn_job_record(self):
         st, bn = self.ctx.st, self.bn
         if not self.bwd_fold and getattr(self, "_bn_scratch", None) is None:
             self._bn_scratch = torch.empty(ops.bn_backward_scratch_floats(self.core.cout), dtype=F32,
                                            device=self.ctx.device)
-        # (the scratch word of a folded job carries its barrier counter: read by the one-launch form only;
-        # + 256: the folded rows hold the sums already, see ops.ConvJobs.add(bnbwd=))
+        # (the scratch word of a folded job carries its barrier counter: read by the one-launch form only)
         return ops.bn_backward_job(self.out.g, self.raw, self.draw, self.save, st.p[bn + ".weight"],
                                    st.p[bn + ".bias"], self.bfold[self.bfold_rows:] if self.bwd_fold else self._bn_scratch,
-                                   st.g[bn + ".weight"], st.g[bn + ".bias"], act=self.act + (256 if self.fed else 0),
-                                   accumulate=self.shared, folded=self.bfold if self.bwd_fold else None)
-
-    def _feed_args(self):
-        """The BatchNorm-backward arguments of the layer below for this layer's data gradient (ops.conv2d_bnbwd)."""
-        f, st = self.feeds, self.ctx.st
-        return (f.raw, f.save, st.p[f.bn + ".weight"], st.p[f.bn + ".bias"], f.act, f.bfold[:f.bfold_rows])
+                                   st.g[bn + ".weight"], st.g[bn + ".bias"], act=self.act, accumulate=self.shared,
+                                   folded=self.bfold if self.bwd_fold else None)
 
     def bwd_dgrad_job(self, jobs: "ops.ConvJobs") -> bool:
         c = self.core
         if not c.need_dx:
             return False
         jobs.add(self.draw, c.wpt, c.xin.g, c.kh, c.kw, c.sh, c.sw, c.ph, c.pw, transposed=not c.deconv,
-                 accumulate=True, bnbwd=self._feed_args() if self.feeds is not None else None)
+                 accumulate=True)
         return True
 
     def backward(self):
@@ -792,27 +774,8 @@ class ConvBN:
     def backward_input(self):
         """xin.g += data gradient; the lane's temp still holds the pre-BN gradient from backward_local()."""
         c = self.core
-        if c.need_dx and self.feeds is not None:
-            bx, save, gamma, beta, act, rows = self._feed_args()
-            ops.conv2d_bnbwd(self.draw, c.wpt, c.xin.g, c.kh, c.kw, c.sh, c.sw, c.ph, c.pw, bx, save, gamma, beta, act,
-                             rows, transposed=not c.deconv, accumulate=True)
-        elif c.need_dx:
+        if c.need_dx:
             c.dgrad(self.draw, c.xin.g)
-
-
-def link_bn_backward(producer: "ConvBN", consumer: "ConvBN"):
-    """`consumer` reads `producer`'s output and nothing else does: the consumer's data gradient, the one writer of the
-    producer's output gradient, then forms the producer's BatchNorm-backward sums in its epilogue, and the producer's
-    backward starts at the apply pass (one read of the gradient and the raw output, and one launch, fewer)."""
-    ctx = producer.ctx
-    if not (BNBWD_FUSE and ctx.grads and ctx.st is not None and ctx.bn_sync is None and producer.bwd_fold
-            and not producer.bwd_one and not producer.shared and not producer.accumulate and not producer.bias_key
-            and consumer.core.need_dx and producer.core.cout % 8 == 0):
-        return
-    a, b = producer.out, consumer.core.xin
-    if not (a.act is b.act and (a.c0, a.c1, a.n0, a.n1) == (b.c0, b.c1, b.n0, b.n1) == (0, a.act.v.C, 0, a.act.v.N)):
-        return
-    consumer.feeds, producer.fed = producer, True
 
 
 class InputGradGroup:
@@ -903,7 +866,11 @@ class InputGradGroup:
 
     def _make_bn_jobs(self):
         st = self.ctx.st
-        rows = [m.bn_job_record() for m in self.members]
+        rows = [ops.bn_backward_job(m.out.g, m.raw, m.draw, m.save, st.p[m.bn + ".weight"], st.p[m.bn + ".bias"],
+                                    m.bfold[m.bfold_rows:] if m.bwd_fold else m._bn_scratch, st.g[m.bn + ".weight"],
+                                    st.g[m.bn + ".bias"], act=m.act, accumulate=m.shared,
+                                    folded=m.bfold if m.bwd_fold else None)
+                for m in self.members]
         self.bn_jobs = torch.tensor(rows, dtype=torch.int64).to(self.ctx.device)
         self.bn_maxc = max(m.core.cout for m in self.members)
         self.npix = self.drawcat.npix
@@ -941,10 +908,7 @@ def bn_jobs_mode(layers, npix: int, maxc: int) -> int:
     """The all_folded argument of ops.bn_backward_jobs for these layers: 0 per-block rows, 1 folded rows (two
     launches), 2 folded rows and one launch with a grid barrier (layers small enough for it)."""
     if not all(l.bwd_fold for l in layers):
-        assert not any(l.fed for l in layers)
         return 0
-    if any(l.fed for l in layers):      # 3: every job's sums are in place already - the apply launch alone
-        return 3 if all(l.fed for l in layers) else 1
     return 2 if BN_BWD_ONE and ops.bn_backward_fused_ok(npix, maxc, len(layers)) else 1
 
 
@@ -962,9 +926,6 @@ POOL_AFTER = not os.environ.get("RIED_NO_POOL_AFTER")      # forward-only plans:
 # 7.81 against 7.79 ms per step - the barrier's atomic round trips cost what the launch boundary they replace costs
 # (43 launches fewer per step; RIED_BN_BWD_ONE=1 turns it on).
 BN_BWD_ONE = bool(os.environ.get("RIED_BN_BWD_ONE"))
-# The data gradient that writes an inner chain layer's output gradient forms that layer's BatchNorm-backward sums in
-# its epilogue (link_bn_backward; RIED_BNBWD_FUSE=0: a reduction launch per layer or level instead).
-BNBWD_FUSE = os.environ.get("RIED_BNBWD_FUSE", "1") != "0"
 
 
 def open_input_grad_group(ctx: Ctx, xin: Slot) -> Optional[InputGradGroup]:
@@ -1306,12 +1267,10 @@ def _chain(ctx: Ctx, seq: Seq, prefix: str, specs, xin: Slot, out: Slot, deconv=
         # forward-only plans: an inner layer whose one consumer runs the general convolution kernel stops at its
         # statistics, and the consumer normalises the raw output itself (no second pass over the tensor)
         defer = not last and _xf_consumer_ok(ctx, specs[i + 1], deconv, Ho, Wo)
-        layer = seq.add(ConvBN(ctx, prefix + "." + name, cin, cout, k, s, p, cur, dst, deconv=deconv,
-                               accumulate=accumulate and last, defer_apply=defer,
-                               xf_src=prev if (prev is not None and prev.defer_apply) else None))
-        if prev is not None:
-            link_bn_backward(prev, layer)
-        prev, cur = layer, dst
+        prev = seq.add(ConvBN(ctx, prefix + "." + name, cin, cout, k, s, p, cur, dst, deconv=deconv,
+                              accumulate=accumulate and last, defer_apply=defer,
+                              xf_src=prev if (prev is not None and prev.defer_apply) else None))
+        cur = dst
     return cur
 
 

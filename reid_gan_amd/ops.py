@@ -94,17 +94,6 @@ def conv2d_signs(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, sign
                           int(stats_post), _stream())
 
 
-def conv2d_bnbwd(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, bn_x: View, save, gamma, beta, act: int,
-                 folded: torch.Tensor, transposed=False, accumulate=False):
-    """conv2d as the data gradient that produces y = the output gradient of a conv -> BatchNorm -> activation layer
-    whose raw convolution output is bn_x: folded (zeroed, bn_backward_folded_floats(y.C)) += that layer's BatchNorm
-    backward sums (what bn_backward_reduce would add from the stored y)."""
-    assert (bn_x.N, bn_x.H, bn_x.W, bn_x.C) == (y.N, y.H, y.W, y.C)
-    lib.ried_conv2d_bnbwd(x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C, kh, kw, sh, sw, ph, pw,
-                          int(transposed), int(accumulate), bn_x.ptr, bn_x.ld, _p(save), _p(gamma), _p(beta), int(act),
-                          _p(folded), _stream())
-
-
 def conv2d_s2_dgrad_c1fold_scratch_floats(nimg, H, W) -> int:
     return lib.ried_conv2d_s2_dgrad_c1fold_scratch_floats(nimg, H, W)
 
@@ -261,23 +250,15 @@ class ConvJobs:
         self.flops = self.bytes = 0.0      # 2 * pixels * Cin * Cout * taps, and each operand once (for reporting)
 
     def add(self, x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, transposed=False, bias=None, act=0,
-            stats=None, accumulate=False, stats_post=0, bnbwd=None):
-        """Arguments as conv2d (statistics only in the folded form, stats_post = 2).  bnbwd: (bn_x, save, gamma, beta,
-        act, folded) of conv2d_bnbwd - the job then also forms the BatchNorm backward sums of y's layer."""
+            stats=None, accumulate=False, stats_post=0):
+        """Arguments as conv2d (statistics only in the folded form, stats_post = 2)."""
         import numpy as np
         assert self.jobs is None
         rec = np.zeros(lib.ried_conv2d_job_bytes(), dtype=np.uint8)
         nb = np.zeros(1, dtype=np.int32)
-        if bnbwd is not None:
-            bx, save, gamma, beta, bact, folded = bnbwd
-            assert bias is None and not act and stats is None and not stats_post
-            lib.ried_conv2d_make_job_bnbwd(rec.ctypes.data, x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W,
-                                           y.C, kh, kw, sh, sw, ph, pw, int(transposed), int(accumulate), bx.ptr, bx.ld,
-                                           _p(save), _p(gamma), _p(beta), int(bact), _p(folded), nb.ctypes.data)
-        else:
-            lib.ried_conv2d_make_job(rec.ctypes.data, x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C,
-                                     kh, kw, sh, sw, ph, pw, int(transposed), _p(bias), act, _p(stats), int(accumulate),
-                                     int(stats_post), nb.ctypes.data)
+        lib.ried_conv2d_make_job(rec.ctypes.data, x.ptr, x.ld, _p(w), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.H, y.W, y.C,
+                                 kh, kw, sh, sw, ph, pw, int(transposed), _p(bias), act, _p(stats), int(accumulate),
+                                 int(stats_post), nb.ctypes.data)
         self.recs.append(rec); self.counts.append(int(nb[0]))
         self.flops += 2.0 * (x.npix if transposed else y.npix) * x.C * y.C * kh * kw
         self.bytes += 2.0 * (x.npix * x.C + w.numel() + y.npix * y.C * (2 if accumulate else 1))

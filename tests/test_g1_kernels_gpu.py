@@ -479,50 +479,6 @@ def test_conv2d_fused_activation_backward_and_bias_sums(cin, cout, s, slope, acc
     close(bias.cpu(), ref.sum((0, 2, 3)), 2e-2, "bias gradient")
 
 
-@pytest.mark.parametrize("cin,cout,k,s,N,H,act,job", [(128, 64, 3, 2, 3, 8, 1, False), (64, 64, 3, 1, 4, 8, 1, False),
-                                                      (96, 48, 1, 1, 2, 8, 2, False), (64, 192, (1, 7), 1, 2, 8, 1, True),
-                                                      (48, 40, 3, 2, 2, 8, 0, True), (64, 32, 4, 2, 2, 16, 1, False)])
-def test_data_gradient_with_batchnorm_backward_sums(cin, cout, k, s, N, H, act, job):
-    """The data gradient that writes a layer's output gradient also forms that layer's BatchNorm-backward sums: rows
-    equal (up to the bf16 rounding of the stored gradient) to what bn_backward_reduce adds from the stored tensor,
-    single call and job-table record, accumulating onto an earlier gradient.  k = 4: the gradient of a stride-2
-    convolution's input seen as the ConvTranspose2d(4, 2, 1) it is."""
-    kh, kw = (k, k) if isinstance(k, int) else k
-    ph, pw = ((kh - 1) // 2, (kw - 1) // 2) if k != 4 else (1, 1)
-    g = r(N, cin, H, H, seed=61)                                   # gradient w.r.t. the consumer's conv output
-    w = r(cin, cout, kh, kw, seed=62, scale=(cin * kh * kw) ** -0.5)
-    Ho = H * s
-    opad = (s - 1) if k != 4 else 0
-    old = r(N, cout, Ho, Ho, seed=63).to(torch.bfloat16).float()
-    ref = F.conv_transpose2d(g, w, None, s, (ph, pw), output_padding=opad) + old
-    x, _, gamma, beta, save = _bn_case(N, cout, Ho, 64)
-    xv, yv, gv = to_view(x), to_view(old), to_view(g)
-    nf = ops.bn_backward_folded_floats(cout)
-    got = torch.zeros(nf, device=DEV)
-    wp = pack(w.permute(1, 0, 2, 3))
-    if job:
-        jobs = ops.ConvJobs()
-        jobs.add(gv, wp, yv, kh, kw, s, s, ph, pw, transposed=True, accumulate=True,
-                 bnbwd=(xv, save, gamma, beta, act, got))
-        jobs.finalize(DEV)
-        jobs.launch()
-    else:
-        ops.conv2d_bnbwd(gv, wp, yv, kh, kw, s, s, ph, pw, xv, save, gamma, beta, act, got, transposed=True,
-                         accumulate=True)
-    close(from_view(yv), ref, what="dgrad")
-    want = torch.zeros(nf, device=DEV)
-    ops.bn_backward_reduce(yv, xv, save, gamma, beta, want, relu=act)
-    rows = ops.lib.ried_bn_bwd_fold_rows()
-    a, b = got.view(rows, 2, cout).sum(0).cpu(), want.view(rows, 2, cout).sum(0).cpu()
-    # against torch too: sum g' and sum g' * x-hat with g' the gradient masked by the activation
-    xh = (x - save[0].cpu().view(1, -1, 1, 1)) * save[1].cpu().view(1, -1, 1, 1)
-    pre = xh * gamma.cpu().view(1, -1, 1, 1) + beta.cpu().view(1, -1, 1, 1)
-    gm = ref * (1.0 if act == 0 else torch.where(pre > 0, 1.0, 0.0 if act == 1 else 0.2))
-    t = torch.stack([gm.sum((0, 2, 3)), (gm * xh).sum((0, 2, 3))])
-    assert (a - b).abs().max() <= 1e-2 * b.abs().max() + 1e-3, (a - b).abs().max().item()
-    assert (a - t).abs().max() <= 1e-2 * t.abs().max() + 1e-3, (a - t).abs().max().item()
-
-
 def _sign_bytes(y_nchw: torch.Tensor) -> torch.Tensor:
     """uint8 [pixels][C/8]: bit q of byte c set where channel 8c + q is positive."""
     N, C, H, W = y_nchw.shape
