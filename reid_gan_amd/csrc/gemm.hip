@@ -19,6 +19,7 @@
 // of every bf16 layer of the generator, discriminator and VGG16 extractor
 // (reference: src/rinet.py:183-205, 131-148; src/loss.py:69-87), and the
 // batched products of the self-attention layers (src/rinet.py:162-181).
+#include <stdlib.h>
 #include "common.h"
 #include "bn_common.h"
 
@@ -2285,6 +2286,12 @@ static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int kstep
     t.bm = 32; t.nst = 2;
     t.bn = (taps > 1 && npix >= 131072) ? 128 : 64;
   }
+  // Short layers on grids that leave the chip under-filled (the generator's 8x8 and 4x4 maps): 32 output channels
+  // per block double the blocks again; measured 6-10 % faster alone (6.7 -> 6.1, 14.0 -> 12.6 us) where K is short.
+  static const bool tile32 = !getenv("RIED_NO_TILE32");
+  if (tile32 && Cout > 32 && t.bm == 64 && t.bn == 64 && t.nst == 2 &&
+      ceil_div(Cout, 64) * ceil_div(npix, 64) * phases <= 384 && ksteps < 24)
+    t.bm = 32;
   if (forced[0] > 0) {
     t.bm = forced[0]; t.bn = forced[1]; t.nst = forced[2];
   }
@@ -2554,7 +2561,8 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   RIED_CONV_CASE8(128, 256, 2) RIED_CONV_CASE8(128, 256, 3) RIED_CONV_CASE8(64, 256, 2) RIED_CONV_CASE8(64, 256, 3)
   RIED_CONV_CASE(128, 128, 2) RIED_CONV_CASE(128, 128, 3) RIED_CONV_CASE(128, 64, 2) RIED_CONV_CASE(128, 64, 3)
   RIED_CONV_CASE(128, 64, 4) RIED_CONV_CASE(64, 128, 2) RIED_CONV_CASE(64, 128, 3) RIED_CONV_CASE(64, 128, 4)
-  RIED_CONV_CASE(64, 64, 2) RIED_CONV_CASE(64, 64, 3) RIED_CONV_CASE(64, 64, 4)
+  RIED_CONV_CASE(64, 64, 2) RIED_CONV_CASE(64, 64, 3) RIED_CONV_CASE(64, 64, 4) RIED_CONV_CASE(64, 64, 6)
+  RIED_CONV_CASE(64, 64, 8)
   RIED_CONV_CASE(32, 128, 2) RIED_CONV_CASE(32, 64, 2)
 #undef RIED_CONV_CASE
 #undef RIED_CONV_CASE8
