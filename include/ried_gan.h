@@ -149,8 +149,9 @@ int ried_conv2d_make_job(void* job_host, const void* x, long long ldx, const voi
                          int* nblocks);
 int ried_conv2d_jobs(const void* jobs, const int* map, int nblocks, ried_stream_t stream);
 /* Reporting aid (no counterpart in the reference): which kernel a ried_conv2d call with these arguments runs, without
- * launching it.  which[4] = {kind, bm, bn or tile side, LDS stages}; kind 0 = conv_glds_kernel<bm, bn, stages>,
- * 1 = conv_halo_kernel<bm, side, stages>, 2 = conv_halo_s2t_kernel<side>, 3 = conv_halo_d4_kernel<bm>. */
+ * launching it.  which[4] = {kind, bm, bn or tile side, LDS stages (+ 10: two K groups per block)}; kind
+ * 0 = conv_glds_kernel<bm, bn, stages>, 1 = conv_halo_kernel<bm, side, stages>, 2 = conv_halo_s2t_kernel<side>,
+ * 3 = conv_halo_d4_kernel<bm>. */
 int ried_conv2d_which(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H, int W,
                       int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int transposed,
                       const float* bias, int act, float* stats, int accumulate, int out_f32, float* y2, long long ldy2,

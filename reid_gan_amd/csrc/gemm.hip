@@ -806,7 +806,11 @@ __device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned byt
 
 // NT threads: 256 (2 x 2 waves) or 512 (2 x 4 waves: twice the pixels per block for the same weight traffic).
 // (bx, by) of (nbx, nby): the block's place in the problem's own grid (the launch grid, or a job's share of one)
-template <int BM, int BN, int NST, int NT>
+// KS = 2 (layers whose grid leaves one block per CU and whose K loop is long): the block has two groups of NT threads,
+// each with its own stage ring, that take alternate stages of K - two waves per SIMD hide each other's LDS and MFMA
+// latency, which is what bounds a block alone on its CU - and the second group hands its accumulators to the first
+// through LDS before the epilogue.
+template <int BM, int BN, int NST, int NT, int KS = 1>
 __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int by, int nbx, int nby, char* smem) {
   constexpr int WN = NT / 128;                        // waves along the pixel axis
   constexpr int RPP = NT / 8;                         // rows per DMA pass (8 lanes = one 128-byte row)
@@ -814,9 +818,12 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
   constexpr int NLA = BM / RPP, NLB = BN / RPP;       // 16-byte DMA loads per lane per stage
   constexpr int STAGE = (BM + BN) * 128;              // bytes per stage: A image then B image
 
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int kg = KS == 1 ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x / NT);      // K group of this wave
+  const int tid = (int)threadIdx.x - kg * NT, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
+  char* const smem0 = smem;
+  smem += kg * (NST * STAGE);
 
   // XCD-aware order: consecutive hardware block ids go round-robin over the 8 XCDs; give each XCD a
   // contiguous run of logical tiles so that the blocks sharing a pixel tile hit one L2.
@@ -838,7 +845,7 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
   }
   const int rstep = X.transposed ? X.sh : 1, sstep = X.transposed ? X.sw : 1;
   const int CPT = P.K >> 3;                             // chunks per tap
-  const int nsteps = (ti_n * tj_n * CPT + 7) >> 3;
+  const int nsteps = (((ti_n * tj_n * CPT + 7) >> 3) + KS - 1) / KS;      // stages per K group (a zero stage may end the last)
 
   // this lane's rows and chunk column
   const int rowp = tid >> 3;
@@ -866,7 +873,7 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
     if (n >= P.N) gy[i] = -(1 << 24);                   // never inside the image
   }
   int c, ti, tj;
-  { int tap = kq / CPT; c = kq - tap * CPT; ti = tap / tj_n; tj = tap - ti * tj_n; }
+  { int k0 = kq + 8 * kg; int tap = k0 / CPT; c = k0 - tap * CPT; ti = tap / tj_n; tj = tap - ti * tj_n; }
 
   char* const lds_wave = smem + wave * 1024;            // + i * NT * 16 per row pass, + BM * 128 for B
   const unsigned ldx2 = (unsigned)X.ld * 2u;
@@ -888,7 +895,7 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
       unsigned bad = ((unsigned)hi < (unsigned)X.H && (unsigned)wi < (unsigned)X.W) ? 0u : GLDS_OOB;
       glds16(rsB, ((unsigned)(pix[i] + dpx) * ldx2 + cb) | bad | inval, dst + BM * 128 + i * (NT * 16));
     }
-    c += 8;
+    c += 8 * KS;
     while (c >= CPT) {
       c -= CPT;
       if (++tj == tj_n) { tj = 0; ++ti; }
@@ -940,6 +947,25 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no DMA may outlive the block or race the epilogue
   __builtin_amdgcn_s_barrier();
+  if constexpr (KS == 2) {      // the second group's sums go to the first through the second group's own ring, then it leaves
+    static_assert(TM * TN * NT * 16 <= NST * STAGE, "accumulator hand-over area");
+    f32x4* dump = reinterpret_cast<f32x4*>(smem0 + NST * STAGE) + tid;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) dump[(i * TN + j) * NT] = acc[i][j];
+    }
+    __syncthreads();
+    if (kg == 1) return;        // (a barrier counts the waves still running: the epilogue's see the first group only)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 o = dump[(i * TN + j) * NT];
+        acc[i][j][0] += o[0]; acc[i][j][1] += o[1]; acc[i][j][2] += o[2]; acc[i][j][3] += o[3];
+      }
+  }
   if (P.E.staged)
     gemm_epilogue_staged<BM, BN, WN, NST * STAGE>(P, acc, m0, LinearRowMap{P, n0, pa, pb}, tn, nbx / P.tiles_m, by,
                                                   smem);
@@ -948,10 +974,10 @@ __device__ __forceinline__ void conv_glds_body(const GemmParams& P, int bx, int 
                                      nbx * nby, smem);
 }
 
-template <int BM, int BN, int NST, int NT = 256>
-__global__ __launch_bounds__(NT) void conv_glds_kernel(const GemmParams P) {
-  __shared__ __attribute__((aligned(1024))) char smem[NST * (BM + BN) * 128];
-  conv_glds_body<BM, BN, NST, NT>(P, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
+template <int BM, int BN, int NST, int NT = 256, int KS = 1>
+__global__ __launch_bounds__(NT * KS) void conv_glds_kernel(const GemmParams P) {
+  __shared__ __attribute__((aligned(1024))) char smem[KS * NST * (BM + BN) * 128];
+  conv_glds_body<BM, BN, NST, NT, KS>(P, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, smem);
 }
 
 // ---------------------------------------------------------------------------
@@ -2240,7 +2266,7 @@ __global__ __launch_bounds__(256) void wgrad_glds_jobs_kernel(const GemmParams* 
 
 // Tile of the convolution kernel for a problem: Cout x pixels per phase.  Small problems take 64-pixel tiles
 // (more blocks than CUs matter more than MFMA efficiency there).
-struct ConvTile { int bm, bn, nst; };
+struct ConvTile { int bm, bn, nst, ks; };      // ks: K groups per block (conv_glds_body)
 static int g_forced_tile[3] = {0, 0, 0};
 // Tuning hook: force the tile (bm, bn, nst) of every later ried_conv2d call in this process; bm = 0 restores the
 // built-in choice; bm = -1 keeps the built-in tiles of the general kernel.  Any non-zero bm turns the halo-tile
@@ -2250,6 +2276,7 @@ extern "C" int ried_conv2d_force_tile(int bm, int bn, int nst) {
   return RIED_OK;
 }
 extern "C" int ried_bn_fold_rows();
+#define KSPLIT_MIN_STEPS 12
 static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int ksteps, int taps) {
   const int* forced = g_forced_tile;
   ConvTile t;
@@ -2257,7 +2284,7 @@ static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int kstep
   // CU are worth more than DMA depth), and the 64-pixel tile wins whenever the 128-pixel grid would leave CUs
   // idle or end in a mostly empty last round.  Model: time ~ rounds over the resident-block slots x tile cost.
   t.bm = Cout <= 64 ? 64 : 128;
-  t.nst = 2;
+  t.nst = 2; t.ks = 1;
   const long long tiles_m = ceil_div(Cout, t.bm);
   const long long b128 = tiles_m * ceil_div(npix, 128) * phases, b64 = tiles_m * ceil_div(npix, 64) * phases;
   const int cus = 256;
@@ -2289,11 +2316,21 @@ static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int kstep
   // Short layers on grids that leave the chip under-filled (the generator's 8x8 and 4x4 maps): 32 output channels
   // per block double the blocks again; measured 6-10 % faster alone (6.7 -> 6.1, 14.0 -> 12.6 us) where K is short.
   static const bool tile32 = !getenv("RIED_NO_TILE32");
-  if (tile32 && Cout > 32 && t.bm == 64 && t.bn == 64 && t.nst == 2 &&
-      ceil_div(Cout, 64) * ceil_div(npix, 64) * phases <= 384 && ksteps < 24)
+  const long long tiles64 = ceil_div(Cout, 64) * ceil_div(npix, 64) * phases;
+  if (tile32 && Cout > 32 && t.bm == 64 && t.bn == 64 && t.nst == 2 && tiles64 <= 384 && ksteps < 24)
     t.bm = 32;
-  if (forced[0] > 0) {
-    t.bm = forced[0]; t.bn = forced[1]; t.nst = forced[2];
+  // One block per CU at most and a long K loop: two K groups per block (measured alone on the VGG16 conv5 layers of
+  // the perceptual loss at 4 x 4 maps, 72 stages: see conv_glds_body).
+  static const bool ksplit = !getenv("RIED_NO_KSPLIT");
+  if (ksplit && t.bm == 64 && t.bn == 64) {
+    // measured alone (us, one group -> two): conv5 of VGG16 at 4 x 4 maps 28.2 -> 20.9 (three stages; 26.1 with two),
+    // 3 x 3 224 -> 192 at 4 x 4 14.0 -> 10.8, 1 x 7 128 -> 128 at 8 x 8 9.0 -> 7.9, and with two blocks per CU the
+    // discriminator's 3 x 3 stride-2 512 -> 512 at 8 x 8 35.0 -> 31.7
+    if (tiles64 <= 256 && ksteps >= KSPLIT_MIN_STEPS) { t.ks = 2; t.nst = ksteps >= 48 ? 3 : 2; }
+    else if (tiles64 <= 512 && ksteps >= 48 && phases == 1) { t.ks = 2; t.nst = 2; }
+  }
+  if (forced[0] > 0) {       // (nst + 10: two K groups)
+    t.bm = forced[0]; t.bn = forced[1]; t.nst = forced[2] % 10; t.ks = forced[2] >= 10 ? 2 : 1;
   }
   return t;
 }
@@ -2416,7 +2453,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   if (job && !which) {
     RIED_CHECK_ARG(!fin && !img_stats && (!stats || P.E.stats_fold),
                    "ried_conv2d_make_job: statistics must be the folded form (stats_post = 2)");
-    t.bm = 64; t.bn = 64; t.nst = 2;
+    t.bm = 64; t.bn = 64; t.nst = 2; t.ks = 1;
     P.tiles_m = ceil_div(Cout, t.bm);
     P.grid[0] = P.tiles_m * ceil_div(npix, t.bn); P.grid[1] = phases; P.grid[2] = 1;
     memcpy(job->rec, &P, sizeof(P));
@@ -2529,7 +2566,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
   }
   P.tiles_m = ceil_div(Cout, t.bm);
   dim3 grid(P.tiles_m * ceil_div(npix, t.bn), phases, 1);
-  if (which) { which[0] = 0; which[1] = t.bm; which[2] = t.bn; which[3] = t.nst; return RIED_OK; }
+  if (which) { which[0] = 0; which[1] = t.bm; which[2] = t.bn; which[3] = t.nst + 10 * (t.ks - 1); return RIED_OK; }
   if (fin) {
     P.E.fin = *fin;
     P.E.fin.nrows = phases * ceil_div(npix, t.bn);
@@ -2556,6 +2593,15 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
 #undef RIED_XF_CASE
     RIED_CHECK_ARG(launched, "ried_conv2d_xf: no kernel for tile %dx%d", t.bm, t.bn);
     RIED_CHECK_LAUNCH("ried_conv2d_xf");
+    return RIED_OK;
+  }
+  if (t.ks == 2) {
+    RIED_CHECK_ARG(t.bm == 64 && t.bn == 64 && (t.nst == 2 || t.nst == 3 || t.nst == 4),
+                   "ried_conv2d: two K groups only with 64 x 64 tiles");
+    if (t.nst == 2) hipLaunchKernelGGL((conv_glds_kernel<64, 64, 2, 256, 2>), grid, dim3(512), 0, stream, P);
+    else if (t.nst == 3) hipLaunchKernelGGL((conv_glds_kernel<64, 64, 3, 256, 2>), grid, dim3(512), 0, stream, P);
+    else hipLaunchKernelGGL((conv_glds_kernel<64, 64, 4, 256, 2>), grid, dim3(512), 0, stream, P);
+    RIED_CHECK_LAUNCH("ried_conv2d");
     return RIED_OK;
   }
   RIED_CONV_CASE8(128, 256, 2) RIED_CONV_CASE8(128, 256, 3) RIED_CONV_CASE8(64, 256, 2) RIED_CONV_CASE8(64, 256, 3)
@@ -2646,7 +2692,7 @@ extern "C" int ried_conv2d_make_job(void* job_host, const void* x, long long ldx
                      nullptr, 0, 0.f, &job);
 }
 // Which kernel a ried_conv2d call with these arguments runs (for reports): which[4] = {kind, bm, bn or tile side,
-// LDS stages}; kind 0 = conv_glds_kernel<bm, bn, stages>, 1 = conv_halo_kernel<bm, side, stages>,
+// LDS stages (+ 10: two K groups per block)}; kind 0 = conv_glds_kernel<bm, bn, stages>, 1 = conv_halo_kernel<bm, side, stages>,
 // 2 = conv_halo_s2t_kernel<side>, 3 = conv_halo_d4_kernel<bm>.  Nothing is launched.
 extern "C" int ried_conv2d_which(const void* x, long long ldx, const void* w, void* y, long long ldy, int nimg, int H,
                                  int W, int Cin, int Ho, int Wo, int Cout, int kh, int kw, int sh, int sw, int ph,

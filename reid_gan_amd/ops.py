@@ -142,6 +142,8 @@ def conv2d_which(x: View, w: torch.Tensor, y: View, kh, kw, sh, sw, ph, pw, tran
                           None if mask is None else mask.ptr, 0 if mask is None else mask.ld, mask_slope,
                           int(stats_post), ctypes.addressof(which))
     kind, bm, bn, nst = list(which)
+    if kind == 0 and nst >= 10:      # two K groups per block
+        return f"conv_glds_kernel<{bm},{bn},{nst - 10},256,2>"
     return (f"conv_glds_kernel<{bm},{bn},{nst}>", f"conv_halo_kernel<{bm},{bn},{nst}>", f"conv_halo_s2t_kernel<{bn}>",
             f"conv_halo_d4_kernel<{bm}>", f"conv_halo_s2f_kernel<{bm}>")[kind]
 
