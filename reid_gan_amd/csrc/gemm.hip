@@ -2306,6 +2306,12 @@ static ConvTile choose_conv_tile(int Cout, long long npix, int phases, int kstep
     t.bm = Cout >= 256 ? 128 : 64;
     // measured exception (512x512 inference, deconv1: 4 phases of 128x128 maps, 64 output channels): 383 vs 506 us
     if (phases > 1 && Cout == 64 && npix >= (1 << 19)) t.bn = 128;
+    // the heaviest 1x1 layers (512x512 inference: 256 -> 224 at 128x128 maps, 512 -> 512 at 64x64) stream their
+    // operands once and want more bytes in flight: 128 channels per block and three stages, 223 -> 193 and 136 -> 122 us
+    static const bool big1x1 = !getenv("RIED_NO_BIG1X1");
+    if (big1x1 && taps == 1 && phases == 1 && Cout >= 192 && (double)npix * ksteps * 64.0 * Cout >= 2.5e10) {
+      t.bm = 128; t.nst = 3;
+    }
   }
   // Layers with at most 32 output channels (the narrow Inception branches, deconv2): 32-row tiles waste no MFMA
   // rows and measured 10-30 % faster everywhere; 128 pixels per block only for multi-tap layers on large maps.

@@ -26,13 +26,14 @@ def run(N, H, W, Cin, Cout, kh, kw, s, tr, reps=20):
     w = torch.randn(Cout * kh * kw * Cin, device="cuda").to(torch.bfloat16)
     out = {}
     stats = None
-    if os.environ.get("TUNE_STATS"):        # with the BatchNorm statistics rows in the epilogue
-        rows = ops.conv2d_stat_rows(N, Ho, Wo, Cin, Cout, kh, kw, s, s, bool(tr))
-        stats = torch.zeros(rows * 2 * Cout, device="cuda")
     for cfg in CONFIGS:
         if Cout <= 64 and cfg[0] > 64:
             continue
         lib.ried_conv2d_force_tile(*cfg)
+        if os.environ.get("TUNE_STATS"):    # with the BatchNorm statistics rows in the epilogue (one row per pixel tile
+            # of the FORCED shape: sized after forcing it - the library cannot check the caller's buffer)
+            rows = ops.conv2d_stat_rows(N, Ho, Wo, Cin, Cout, kh, kw, s, s, bool(tr))
+            stats = torch.zeros(rows * 2 * Cout, device="cuda")
         try:
             f = lambda: ops.conv2d(x, w, y, kh, kw, s, s, ph, pw, transposed=bool(tr), stats=stats)
             f(); torch.cuda.synchronize()
