@@ -141,6 +141,7 @@ class Ctx:
         self.dx_group: Optional["InputGradGroup"] = None     # open group of sibling 1x1 layers (see InputGradGroup)
         self.build_lane = 0                # lane (stream + scratch set) the layers being built will run on
         self.packs = ops.JobTable(13)      # every weight repack of the plan: one launch (pack_all)
+        self.repack = True                 # False (frozen weights: inference engines): begin_forward() packs nothing
         self.nine: Optional[torch.Tensor] = None      # device scalar 9.0 (divisor of the pool-folded weights)
         self.splitk_target, self.splitk_minpix = 0, 0      # 0: the defaults of _splitk (a launch per layer)
         self.splitk_whole_rounds = False                   # True: split counts that fill whole rounds of the chip (see _splitk)
@@ -271,7 +272,8 @@ class Ctx:
         ops.pack_jobs(self.packs)
 
     def begin_forward(self):
-        self.pack_all()          # per-tile partial-sum rows need no clearing: the conv epilogues overwrite them
+        if self.repack:
+            self.pack_all()      # per-tile partial-sum rows need no clearing: the conv epilogues overwrite them
         if self.fold_elems and self.training:
             self.fold_arena.zero_()
 

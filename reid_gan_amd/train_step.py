@@ -621,6 +621,21 @@ class InferenceEngine:
         self.x = torch.zeros(batch, 1, H, W, dtype=F32, device=device)
         self.y = torch.zeros(batch, 1, H, W, dtype=F32, device=device)
         self.use_graph, self.graph = use_graph, None
+        self.refresh_weights()
+
+    def refresh_weights(self, g_sd: Optional[Dict[str, torch.Tensor]] = None):
+        """The weights of an evaluation loop do not change between batches, so their packed bf16 copies are built here,
+        once, and not at the head of every pass (a launch over every weight of the network).  Call again - with a state
+        dict to load, or right after writing into self.gs - when they do change (until then the layers that read the
+        fp32 weights directly see the new values and the others the old)."""
+        for st, plan in self._plans():
+            if g_sd is not None:
+                st.load_state_dict(g_sd)
+            plan.ctx.pack_all()
+            plan.ctx.repack = bool(os.environ.get("RIED_INFER_REPACK"))      # (A/B switch: pack at every pass again)
+
+    def _plans(self):
+        return [(self.gs, self.G)]
 
     def _body(self):
         pred = self.G.forward(self.x)
@@ -704,6 +719,10 @@ class SliceInference(InferenceEngine):
         self.G = self.plans[0]
         self._engine = engine
         self.use_graph, self.graph = use_graph, None
+        self.refresh_weights()
+
+    def _plans(self):
+        return list(zip(self.states, self.plans))
 
     def _body(self):
         eng = self._engine

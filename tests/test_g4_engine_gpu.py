@@ -476,6 +476,27 @@ def test_gradient_buckets_follow_the_state_dict_order(monkeypatch):
     grad_close(a, b, "two buckets vs one", cos=0.995, ratio=0.03)
 
 
+def test_inference_engine_packs_its_weights_once_and_on_request():
+    """The engine builds the packed weights when it is made, not at every pass: new weights take effect through
+    refresh_weights() - and then the engine equals one built from them."""
+    sd = g_state()
+    B, H = 2, 64
+    x, y = synth_batch(B, H, seed=57)
+    eng = InferenceEngine(sd, B, H, H)
+    first = eng.run(x.to(DEV), y.to(DEV))[0].cpu().clone()
+    sd2 = {k: (v * 1.25 if k.endswith("conv.weight") or k.endswith("deconv.weight") else v.clone()) for k, v in sd.items()}
+    # (between a write into the masters and refresh_weights() the engine is in no defined state: the layers that read
+    # fp32 weights directly - the first and the last - already see the new ones)
+    eng.gs.load_state_dict({k: v for k, v in sd2.items() if k in eng.gs.p})
+    eng.refresh_weights()
+    fresh = eng.run(x.to(DEV), y.to(DEV))[0].cpu().clone()
+    want = InferenceEngine(sd2, B, H, H).run(x.to(DEV), y.to(DEV))[0].cpu()
+    act_close(fresh, want, "after refresh_weights", mx=5e-3, mean=5e-4)
+    assert (fresh - first).abs().mean() > 1e-2 * first.abs().mean()
+    eng.refresh_weights(sd)                       # a state dict to load
+    act_close(eng.run(x.to(DEV), y.to(DEV))[0].cpu(), first, "back to the first weights", mx=5e-3, mean=5e-4)
+
+
 def test_slice_inference_is_the_batch_one_loop():
     """SliceInference: every slice normalised with its own statistics, as the reference's batch-1 evaluation loop
     does - against the batch-1 engine slice by slice, against the oracle's forward of each slice alone, and unlike
