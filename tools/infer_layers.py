@@ -1,12 +1,15 @@
-"""Every distinct convolution of the 512 x 512 inference batch (32 slices) under the library's own dispatch: kernel
-template, time alone (graph replay of 20 launches), TFLOP/s and algorithmic GB/s (input + output + weights once)."""
+"""Every distinct convolution of the 512 x 512 inference batch (32 slices) - or, with the argument "step", of the
+training step at batch 128 - under the library's own dispatch: kernel template, time alone (graph replay of 20
+launches), TFLOP/s and algorithmic GB/s (input + output + weights once)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from reid_gan_amd import ops
+STEP = sys.argv[1:] == ["step"]
+sys.argv = sys.argv[:1]                  # (conv_tune reads a shape file named by its own first argument)
 import conv_tune
 
-shapes = conv_tune.gather_infer_shapes()
+shapes = conv_tune.gather_shapes() if STEP else conv_tune.gather_infer_shapes()
 rows = []
 for N, H, W, Cin, Cout, kh, kw, s, tr, cnt in shapes:
     ph, pw = ((kh - 1) // 2, (kw - 1) // 2) if kh != 4 else (1, 1)
