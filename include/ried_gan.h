@@ -98,6 +98,12 @@ int ried_conv2d_bn(const void* x, long long ldx, const void* w, void* y, long lo
 int ried_conv2d_tap_mse(const void* x, long long ldx, const void* w, const float* bias, void* y, long long ldy,
                         int nimg, int H, int W, int Cin, int Cout, const float* target, long long ld_target, void* gout,
                         long long ld_gout, float gscale, float* stats, ried_stream_t stream);
+/* The same with the target's tap given as its stored bf16 activations (a view of the target half of the feature map,
+ * ld_target elements per pixel) instead of an fp32 copy: the target pass writes no fp32 taps and this pass reads half
+ * the bytes; d is taken against the rounded target values.  All views 16-byte aligned with pitches divisible by 8. */
+int ried_conv2d_tap_mse_bf16(const void* x, long long ldx, const void* w, const float* bias, void* y, long long ldy,
+                             int nimg, int H, int W, int Cin, int Cout, const void* target, long long ld_target,
+                             void* gout, long long ld_gout, float gscale, float* stats, ried_stream_t stream);
 /* out[0] += scale * sum over rows and channels of stats[r][which][c] */
 int ried_stat_rows_total(const float* stats, int nrows, int C, int which, float scale, float* out,
                          ried_stream_t stream);

@@ -62,6 +62,7 @@ struct GemmEpilogue {
   int stats_rows;          //        launch writes; the writer of row t also zeroes rows stats_rows + t*(f-1) .. + f-2
   BnFinalize fin;          // fin.counter != null: the last block to finish turns the stats rows into BN statistics
   const float* sub;        // perceptual-loss tap: d = value - sub[row][m] (the target's features, fp32);
+  int sub_bf16;            //   1: `sub` points at bf16 values (the target's stored activations), ld_sub in elements
   long long ld_sub;        //   stats rows = column sums of d and d*d, gout[row][m] = gscale * d (the seed of the
   bf16_t* gout;            //   tap's gradient); the value itself is still stored as the layer's output
   long long ld_gout;
@@ -565,8 +566,15 @@ __device__ __forceinline__ void gemm_epilogue_staged(const GemmParams& P, f32x4 
         *reinterpret_cast<f32x4*>(o2 + 4) = f32x4{v[4], v[5], v[6], v[7]};
       }
       if (E.sub) {
-        const float* tp = E.sub + orow * E.ld_sub + m;
-        const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+        f32x4 t0, t1;
+        if (E.sub_bf16) {
+          const u32x4 tb = *reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(E.sub) + orow * E.ld_sub + m);
+          t0 = f32x4{bflo(tb[0]), bfhi(tb[0]), bflo(tb[1]), bfhi(tb[1])};
+          t1 = f32x4{bflo(tb[2]), bfhi(tb[2]), bflo(tb[3]), bfhi(tb[3])};
+        } else {
+          const float* tp = E.sub + orow * E.ld_sub + m;
+          t0 = *reinterpret_cast<const f32x4*>(tp); t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+        }
         float d[8] = {v[0] - t0[0], v[1] - t0[1], v[2] - t0[2], v[3] - t0[3],
                       v[4] - t1[0], v[5] - t1[1], v[6] - t1[2], v[7] - t1[3]};
 #pragma unroll
@@ -2394,7 +2402,7 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                        int stats_post, const BnFinalize* fin, hipStream_t stream, const float* sub = nullptr,
                        long long ld_sub = 0, void* gout = nullptr, long long ld_gout = 0, float gscale = 0.f,
                        const ConvJobOut* job = nullptr, const ConvXf* xf = nullptr, int mask_bits = 0,
-                       const ConvFold* fold = nullptr) {
+                       const ConvFold* fold = nullptr, int sub_bf16 = 0) {
   RIED_CHECK_ARG(x && w && (y || fold), "ried_conv2d: null pointer");
   RIED_CHECK_ARG(nimg > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "ried_conv2d: bad spatial dims");
   RIED_CHECK_ARG(Cin % 8 == 0 && Cout % 8 == 0 && ldx % 8 == 0 && ldy % 4 == 0 && Cin <= ldx && Cout <= ldy,
@@ -2446,9 +2454,11 @@ static int conv2d_impl(const void* x, long long ldx, const void* w, void* y, lon
                           ((uintptr_t)gout % 8) == 0),
                  "ried_conv2d: bad perceptual-tap arguments");
   P.E.sub = sub; P.E.ld_sub = ld_sub; P.E.gout = (bf16_t*)gout; P.E.ld_gout = ld_gout; P.E.gscale = gscale;
+  P.E.sub_bf16 = sub_bf16;
   P.E.staged = !fin && !out_f32 && ldy % 8 == 0 && ((uintptr_t)y % 16) == 0 &&
                (!mask || mask_bits || (ldmask % 8 == 0 && ((uintptr_t)mask % 16) == 0)) && (!y2 || ((uintptr_t)y2 % 16) == 0) &&
                (!gout || (ld_gout % 8 == 0 && ((uintptr_t)gout % 16) == 0)) && g_forced_tile[2] != -1;
+  RIED_CHECK_ARG(!sub_bf16 || P.E.staged, "ried_conv2d_tap_mse_bf16: needs the staged epilogue (aligned bf16 views)");
   long long a_bytes = (long long)Cout * kh * kw * Cin * 2;
   long long b_bytes = (((long long)nimg * H * W - 1) * ldx + Cin) * 2;
   RIED_CHECK_ARG(a_bytes < (long long)GLDS_OOB - (1 << 28) && b_bytes < (long long)GLDS_OOB,
@@ -2806,6 +2816,21 @@ extern "C" int ried_conv2d_tap_mse(const void* x, long long ldx, const void* w, 
   RIED_CHECK_ARG(target && gout && stats, "ried_conv2d_tap_mse: null pointer");
   return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, 0, bias, 1, stats, 0, 0,
                      nullptr, 0, nullptr, 0, 0.f, 0, nullptr, stream, target, ld_target, gout, ld_gout, gscale);
+}
+
+// The same with the target's tap given as its stored bf16 activations (a view: ld_target elements per pixel) instead of
+// an fp32 copy: the target pass then writes no fp32 taps and this pass reads half the bytes.  The difference is taken
+// against the rounded target values (relative error 2^-9 per value, the error every other activation already carries).
+extern "C" int ried_conv2d_tap_mse_bf16(const void* x, long long ldx, const void* w, const float* bias, void* y,
+                                        long long ldy, int nimg, int H, int W, int Cin, int Cout, const void* target,
+                                        long long ld_target, void* gout, long long ld_gout, float gscale, float* stats,
+                                        hipStream_t stream) {
+  RIED_CHECK_ARG(target && gout && stats && ld_target % 8 == 0 && ld_target >= Cout && ((uintptr_t)target % 16) == 0 &&
+                     ldy % 8 == 0 && ((uintptr_t)y % 16) == 0 && ld_gout % 8 == 0 && ((uintptr_t)gout % 16) == 0,
+                 "ried_conv2d_tap_mse_bf16: null pointer or unaligned view");
+  return conv2d_impl(x, ldx, w, y, ldy, nimg, H, W, Cin, H, W, Cout, 3, 3, 1, 1, 1, 1, 0, bias, 1, stats, 0, 0,
+                     nullptr, 0, nullptr, 0, 0.f, 0, nullptr, stream, (const float*)target, ld_target, gout, ld_gout, gscale,
+                     nullptr, nullptr, 0, nullptr, 1);
 }
 
 // Weight gradient partial sums.  g: the tensor that is gathered through the kernel window

@@ -1955,6 +1955,9 @@ class Vgg:
         (src/loss.py:179-180); MPL feeds the raw images (src/loss.py:36,101-102)."""
         self.ctx = ctx = Ctx(None, device, grads, training=False)
         self.B, self.H, self.W = B, H, W
+        # True (set by the training step): forward_pred_fused() compares with the target half's stored bf16 activations
+        # and the target pass (forward(..., taps32=False)) writes no fp32 taps
+        self.bf16_targets = False
         self.in_scale, self.in_shift = (1.0 / 4096.0, 0.25) if normalize else (1.0, 0.0)
         N = 2 * B
         dev = device
@@ -1998,10 +2001,12 @@ class Vgg:
         ctx.finalize()
         torch.cuda.synchronize()
 
-    def forward(self, imgs: torch.Tensor, n0: int = 0, n1: Optional[int] = None, src0: Optional[int] = None):
+    def forward(self, imgs: torch.Tensor, n0: int = 0, n1: Optional[int] = None, src0: Optional[int] = None,
+                taps32: bool = True):
         """imgs: fp32 (2B,1,H,W): prediction images first, then targets.  Only images [n0, n1) are processed, so
         the target half can run early, beside other work, and the prediction half once it exists.  With src0 the
-        images are read from imgs[src0 : src0 + n1 - n0] instead (a tensor that holds only one of the halves)."""
+        images are read from imgs[src0 : src0 + n1 - n0] instead (a tensor that holds only one of the halves).
+        taps32=False: no fp32 copies of the taps (bf16_targets)."""
         n1 = 2 * self.B if n1 is None else n1
         a0 = self.a0.images(n0, n1)
         src = imgs[n0:n1] if src0 is None else imgs[src0:src0 + n1 - n0]
@@ -2014,7 +2019,7 @@ class Vgg:
             else:
                 _, core, bias, out, tap32 = l[:5]
                 ops.conv2d(core.xin.images(n0, n1).v, core.wp, out.images(n0, n1).v, 3, 3, 1, 1, 1, 1, bias=bias, act=1,
-                           y2=None if tap32 is None else tap32[n0:n1])
+                           y2=None if (tap32 is None or not taps32) else tap32[n0:n1])
 
     def forward_pred_fused(self, imgs: torch.Tensor, weight: float):
         """The prediction half (images [0, B)) with the perceptual MSE against the target half's fp32 taps (which
@@ -2035,8 +2040,12 @@ class Vgg:
                 ops.conv2d(core.xin.images(0, B).v, core.wp, o.v, 3, 3, 1, 1, 1, 1, bias=bias, act=1)
             else:
                 n = o.v.npix * o.v.C
-                ops.conv2d_tap_mse(core.xin.images(0, B).v, core.wp, bias, o.v, tap32[B:], o.g,
-                                   2.0 * weight / (n * len(self.taps)), core.mse_stats)
+                if self.bf16_targets:
+                    ops.conv2d_tap_mse_bf16(core.xin.images(0, B).v, core.wp, bias, o.v, out.images(B, 2 * B).v, o.g,
+                                            2.0 * weight / (n * len(self.taps)), core.mse_stats)
+                else:
+                    ops.conv2d_tap_mse(core.xin.images(0, B).v, core.wp, bias, o.v, tap32[B:], o.g,
+                                       2.0 * weight / (n * len(self.taps)), core.mse_stats)
 
     def loss_from_rows(self, loss: torch.Tensor):
         """loss[0] += mean over taps of MSE(tap(pred), tap(target)) from the rows forward_pred_fused() left."""

@@ -156,6 +156,14 @@ def conv2d_tap_mse(x: View, w: torch.Tensor, bias: torch.Tensor, y: View, target
                             gout.ptr, gout.ld, gscale, _p(stats), _stream())
 
 
+def conv2d_tap_mse_bf16(x: View, w: torch.Tensor, bias: torch.Tensor, y: View, target: View, gout: View,
+                        gscale: float, stats: torch.Tensor):
+    """conv2d_tap_mse against the target's stored bf16 activations (a view shaped like y)."""
+    assert (target.N, target.H, target.W, target.C) == (y.N, y.H, y.W, y.C)
+    lib.ried_conv2d_tap_mse_bf16(x.ptr, x.ld, _p(w), _p(bias), y.ptr, y.ld, x.N, x.H, x.W, x.C, y.C, target.ptr,
+                                 target.ld, gout.ptr, gout.ld, gscale, _p(stats), _stream())
+
+
 def stat_rows_total(stats: torch.Tensor, nrows: int, C: int, which: int, scale: float, out: torch.Tensor):
     """out[0] += scale * sum over rows and channels of stats[r][which][c]."""
     lib.ried_stat_rows_total(_p(stats), nrows, C, which, scale, _p(out), _stream())

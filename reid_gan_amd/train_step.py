@@ -66,6 +66,10 @@ _RETAINED_GRAPHS = []
 # pinned-memory thread is another such caller.  "thread_local" confines the check to the capturing thread, which is
 # the only one that launches into the captured streams.
 CAPTURE_MODE = "thread_local"
+# The perceptual loss compares the prediction's taps (fp32, before rounding) with the target's STORED bf16 activations
+# instead of an fp32 copy of them: the target pass writes no fp32 taps (256 MB per step at batch 128) and the tap layers
+# read half the bytes.  RIED_VGG_BF16_TARGETS=0: the fp32 copies.
+VGG_BF16_TARGETS = os.environ.get("RIED_VGG_BF16_TARGETS", "1") != "0"
 
 
 def _free_graphs() -> bool:
@@ -155,6 +159,7 @@ class TrainStep:
                            bn_sync=self.xch.sync if self.sync_bn else None)
         self.D = Discriminator(self.ds, 2 * B, H, W, grads=True, training=True, device=device)
         self.V = Vgg(vgg, B, H, W, grads=True, device=device)
+        self.V.bf16_targets = VGG_BF16_TARGETS
         self.x = torch.zeros(B, 1, H, W, dtype=F32, device=device)
         self.y = self.d_in[:B]
         self.dpred = torch.zeros(B, 1, H, W, dtype=F32, device=device)
@@ -359,7 +364,7 @@ class TrainStep:
         if weights:
             self.D.prepare()
         if self.la_vgg:
-            self.V.forward(self.y, B, 2 * B, src0=0)
+            self.V.forward(self.y, B, 2 * B, src0=0, taps32=not VGG_BF16_TARGETS)
         if self.la_dreal:
             self.D.forward_images(self.d_in, 0, B)
 
@@ -395,7 +400,7 @@ class TrainStep:
             if not self.la_vgg:
                 self._vgg_side = self._fork(VGG_LANE, self.overlap_vgg)
                 with torch.cuda.stream(self._vgg_side):
-                    self.V.forward(self.y, B, 2 * B, src0=0)
+                    self.V.forward(self.y, B, 2 * B, src0=0, taps32=not VGG_BF16_TARGETS)
             side = None
             if self.pre_dreal and not self.la_dreal:
                 side = self._fork(DBWD_LANE)
@@ -417,7 +422,7 @@ class TrainStep:
         with torch.cuda.stream(self._vgg_side):
             if self._d_prepared:
                 self.D.prepare()
-            self.V.forward(self.y, B, 2 * B, src0=0)
+            self.V.forward(self.y, B, 2 * B, src0=0, taps32=not VGG_BF16_TARGETS)
         # The first discriminator iteration's weight preparation (spectral norms, packing) and its forward pass on
         # the TARGET images need nothing the generator computes: they run beside the generator forward too, whose
         # small dependent kernels leave most of the chip idle.

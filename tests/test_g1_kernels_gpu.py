@@ -479,6 +479,37 @@ def test_conv2d_fused_activation_backward_and_bias_sums(cin, cout, s, slope, acc
     close(bias.cpu(), ref.sum((0, 2, 3)), 2e-2, "bias gradient")
 
 
+@pytest.mark.parametrize("cin,cout,N,H,bf16", [(64, 64, 2, 16, False), (64, 64, 2, 16, True), (128, 256, 3, 8, True),
+                                               (256, 512, 4, 4, True), (256, 512, 4, 4, False)])
+def test_tap_layer_with_the_perceptual_mse_fused(cin, cout, N, H, bf16):
+    """A VGG tap layer on the prediction images: y = relu(conv + bias), d = y (fp32) - target, column sums of d and
+    d^2, gout = gscale * d - against torch, with the target as an fp32 tensor or as stored bf16 activations (halo
+    kernels on 16 x 16 and 8 x 8 maps, the general kernel on 4 x 4)."""
+    x = r(N, cin, H, H, seed=71)
+    w = r(cout, cin, 3, 3, seed=72, scale=(cin * 9) ** -0.5)
+    b = r(cout, seed=73) * 0.1
+    ref = F.relu(F.conv2d(x, w, b, 1, 1))
+    tgt = (ref + r(N, cout, H, H, seed=74) * 0.05).clamp_min(0).to(torch.bfloat16).float()      # bf16-exact either way
+    d = ref - tgt
+    yv, gv = ops.new_view(N, H, H, cout), ops.new_view(N, H, H, cout)
+    rows = ops.conv2d_stat_rows(N, H, H, cin, cout, 3, 3)
+    stats = torch.full((rows, 2, cout), float("nan"), device=DEV)
+    gscale = 0.37
+    if bf16:
+        ops.conv2d_tap_mse_bf16(to_view(x), pack(w), b.to(DEV), yv, to_view(tgt), gv, gscale, stats)
+    else:
+        t32 = tgt.permute(0, 2, 3, 1).contiguous().to(DEV)
+        ops.conv2d_tap_mse(to_view(x), pack(w), b.to(DEV), yv, t32, gv, gscale, stats)
+    torch.cuda.synchronize()
+    close(from_view(yv), ref, what="tap output")
+    got = from_view(gv)
+    assert (got - gscale * d).abs().max() <= 1.5e-2 * ref.abs().max() * gscale + 4e-3 * (gscale * d).abs().max()
+    tot = stats.sum(0).cpu()
+    assert torch.isfinite(tot).all()
+    close(tot[0], d.sum((0, 2, 3)), 2e-2, "sum d")
+    close(tot[1], (d * d).sum((0, 2, 3)), 2e-2, "sum d^2")
+
+
 def _sign_bytes(y_nchw: torch.Tensor) -> torch.Tensor:
     """uint8 [pixels][C/8]: bit q of byte c set where channel 8c + q is positive."""
     N, C, H, W = y_nchw.shape
