@@ -5,6 +5,7 @@
 //  * spectral normalisation (one power iteration) and its backward term;
 //  * perceptual MSE taps, hinge / generator loss scalars, constant-gradient fills.
 // Reference: src/rinet.py:20,55,70,131-148; src/loss.py:132-197; torch/nn/utils/spectral_norm.py:92-114.
+#include <stdlib.h>
 #include "common.h"
 
 #define SP_THREADS 256
@@ -358,32 +359,36 @@ __global__ __launch_bounds__(SP_THREADS) void conv_c1_dgrad_kernel(const bf16_t*
     const int wx = live ? (int)(s % WS) * PX : 0;
     const long long t = live ? s / WS : 0;
     const int hy = (int)(t % H), n = (int)(t / H);
-    if (live) {
+    // No divergent control flow: pixels outside the image (and the strips past the end, which sit at strip 0) are
+    // loaded from a clamped address and replaced by zeros with a select.
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        const int ho = hy + 1 - r;
-        if ((unsigned)ho >= (unsigned)H) continue;
-        const bf16_t* rowp = dy + ((long long)(n * H + ho) * W) * lddy + c;
+    for (int r = 0; r < 3; ++r) {
+      const int ho = hy + 1 - r;
+      const bool rok = live && (unsigned)ho < (unsigned)H;
+      const bf16_t* rowp = dy + ((long long)(n * H + (rok ? ho : hy)) * W) * lddy + c;
 #pragma unroll
-        for (int j = 0; j < PX + 2; ++j) {
-          const int wo = wx - 1 + j;
-          if ((unsigned)wo >= (unsigned)W) continue;
-          float g[8];
-          unpack8s(*reinterpret_cast<const u32x4*>(rowp + (long long)wo * lddy), g);
+      for (int j = 0; j < PX + 2; ++j) {
+        const int wo = wx - 1 + j;
+        const bool ok = rok && (unsigned)wo < (unsigned)W;
+        u32x4 raw = *reinterpret_cast<const u32x4*>(rowp + (long long)(ok ? wo : wx) * lddy);
+        raw[0] = ok ? raw[0] : 0u; raw[1] = ok ? raw[1] : 0u; raw[2] = ok ? raw[2] : 0u; raw[3] = ok ? raw[3] : 0u;
+        float g[8];
+        unpack8s(raw, g);
 #pragma unroll
-          for (int k = 0; k < PX; ++k) {
-            const int z = k + 2 - j;                        // dy column wo = (wx + k) + 1 - z
-            if (z < 0 || z > 2) continue;
+        for (int k = 0; k < PX; ++k) {
+          const int z = k + 2 - j;                          // dy column wo = (wx + k) + 1 - z
+          if (z < 0 || z > 2) continue;                     // (compile-time)
 #pragma unroll
-            for (int q = 0; q < 8; ++q) acc[k] += g[q] * wl[r * 3 + z][c + q];
-          }
+          for (int q = 0; q < 8; ++q) acc[k] += g[q] * wl[r * 3 + z][c + q];
         }
       }
     }
+    static_assert(CC == 8, "the lane-group sum below is for eight lanes");
 #pragma unroll
-    for (int k = 0; k < PX; ++k) {
-#pragma unroll
-      for (int o = CC / 2; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o, 64);
+    for (int k = 0; k < PX; ++k) {      // sum over the strip's eight lanes, DPP only (no LDS-crossbar shuffles)
+      acc[k] += dpp_mov<0xB1>(acc[k]);  // quad_perm [1,0,3,2]
+      acc[k] += dpp_mov<0x4E>(acc[k]);  // quad_perm [2,3,0,1]
+      acc[k] += dpp_mov<0x141>(acc[k]); // row_half_mirror: the other quad of the eight (its lanes all hold its sum)
     }
     if (cc == 0 && live) {
       float* o = dx + (long long)(n * H + hy) * W + wx;
@@ -399,7 +404,8 @@ extern "C" int ried_conv_c1_dgrad(const void* dy, long long lddy, const float* w
   RIED_CHECK_ARG(lddy % 8 == 0 && lddy >= Cout && ((uintptr_t)dy % 16) == 0, "ried_conv_c1_dgrad: dy view");
   RIED_CHECK_ARG(Cout == 64, "ried_conv_c1_dgrad: Cout must be 64");
   long long npix = (long long)nimg * H * W;
-  if (W % 4 == 0)          // (strips of 8 measured slower: 83 vs 64 us on 256 x 64 x 64)
+  static const bool px1 = getenv("RIED_C1D_PX1") != nullptr;
+  if (W % 4 == 0 && !px1)  // (strips of 8 measured slower: 83 vs 64 us on 256 x 64 x 64)
     hipLaunchKernelGGL((conv_c1_dgrad_kernel<64, 4>), dim3(ew_grid(npix / 4, 32, 8192)), dim3(SP_THREADS), 0, stream,
                        (const bf16_t*)dy, lddy, w, sigma, dx, nimg, H, W, scale, accumulate);
   else

@@ -70,6 +70,12 @@ CAPTURE_MODE = "thread_local"
 # instead of an fp32 copy of them: the target pass writes no fp32 taps (256 MB per step at batch 128) and the tap layers
 # read half the bytes.  RIED_VGG_BF16_TARGETS=0: the fp32 copies.
 VGG_BF16_TARGETS = os.environ.get("RIED_VGG_BF16_TARGETS", "1") != "0"
+# The perceptual term (VGG16 on the prediction: forward with the fused tap MSE, then its data gradient) needs the
+# generator's output and the target taps, nothing of the discriminator: it runs on a side stream from the end of the
+# generator forward, beside the discriminator's first iteration and second forward, into a gradient image of its own
+# that the generator-loss backward adds in.  Single-graph plans only (a side stream may not stay open across the
+# collectives of a data-parallel step).  RIED_OVERLAP_VGG_PRED=0: in line, after the discriminator's second forward.
+OVERLAP_VGG_PRED = os.environ.get("RIED_OVERLAP_VGG_PRED", "1") != "0"
 
 
 def _free_graphs() -> bool:
@@ -163,6 +169,8 @@ class TrainStep:
         self.x = torch.zeros(B, 1, H, W, dtype=F32, device=device)
         self.y = self.d_in[:B]
         self.dpred = torch.zeros(B, 1, H, W, dtype=F32, device=device)
+        self.dpred_v = torch.zeros(B, 1, H, W, dtype=F32, device=device)      # the perceptual term's share (see OVERLAP_VGG_PRED)
+        self._vggp_side = None
         self.sc = torch.zeros(16, dtype=F32, device=device)
         self.ssim_sums = torch.zeros(B, 4, dtype=F32, device=device)
         self.gmap = torch.empty(3, B, H, W, dtype=F32, device=device)
@@ -372,15 +380,15 @@ class TrainStep:
         B, H, W, sc = self.B, self.H, self.W, self.sc
         pred, y = self.G.out, self.y
         self.dpred.zero_()
-        sc[SC_VGG:SC_SSIM + 1].zero_()
+        sc[SC_SSIM:SC_SSIM + 1].zero_()
         # perceptual term (loss.py:179-189); the target half of the features was started in _body()
-        if self._vgg_side is not None:
-            self._join(self._vgg_side)
-            self._vgg_side = None
-        self.V.ctx.zero_backward()
-        self.V.forward_pred_fused(pred, self.wv)      # the MSE against the target taps rides in the tap layers
-        self.V.loss_from_rows(sc[SC_VGG:])
-        self.V.backward(self.dpred)
+        if self._vggp_side is None:          # (else it has been running since the generator forward: joined below)
+            sc[SC_VGG:SC_VGG + 1].zero_()
+            if self._vgg_side is not None:
+                self._join(self._vgg_side)
+                self._vgg_side = None
+            self.dpred_v.zero_()             # (its own image here too: both forms add the three terms in one order)
+            self._vgg_pred_pass(self.dpred_v)
         # DSSIM term on raw HU (loss.py:191): ssim(target, pred), gradient to pred
         self.ssim_sums.zero_()
         ops.ssim_fwd(pred, None, y, 0.01 ** 2, 0.03 ** 2, self.ssim_sums, gmap=self.gmap)
@@ -391,7 +399,32 @@ class TrainStep:
         self.D.ctx.zero_backward()
         ops.fill(out.g.images(B, 2 * B), -self.wg / n)
         self.D.backward(B, 2 * B, wgrad=False, dimg=self.dpred)
+        if self._vggp_side is not None:
+            self._join(self._vggp_side)
+            self._vggp_side = None
+        ops.axpy_f32(self.dpred, self.dpred_v, 1.0)
         ops.gloss_scalars(sc, self.wv, self.ws, self.wg)
+
+    def _vgg_pred_pass(self, dimg: torch.Tensor):
+        self.V.ctx.zero_backward()
+        self.V.forward_pred_fused(self.G.out, self.wv)      # the MSE against the target taps rides in the tap layers
+        self.V.loss_from_rows(self.sc[SC_VGG:])
+        self.V.backward(dimg)
+
+    def _start_vgg_pred(self):
+        """After the generator forward: the perceptual term on the VGG side stream (see OVERLAP_VGG_PRED)."""
+        self._vggp_side = None
+        if not (OVERLAP_VGG_PRED and not self.segmented):
+            return
+        self.sc[SC_VGG:SC_VGG + 1].zero_()
+        self.dpred_v.zero_()
+        s = self._vgg_side if self._vgg_side is not None else side_stream(VGG_LANE)
+        s.wait_stream(torch.cuda.current_stream())      # the prediction, the two clears (and, in stream order, the target taps)
+        with torch.cuda.stream(s):
+            self._vgg_pred_pass(self.dpred_v)
+        self._vgg_side, self._vggp_side = None, s
+        if os.environ.get("RIED_VGGP_JOIN_NOW"):       # (diagnostic: the side stream, but nothing beside it)
+            self._join(s)
 
     def _body(self):
         B = self.B
@@ -410,6 +443,7 @@ class TrainStep:
             if side is not None:
                 self._join(side)
             assert pred.data_ptr() == self.d_in[B:].data_ptr()
+            self._start_vgg_pred()
             yield from self._d_iteration(last=False)
             yield from self._d_iteration(last=True)
             self.gs.adam(self.lr)
@@ -439,6 +473,7 @@ class TrainStep:
             self._join(self._vgg_side)
             self._vgg_side = None
         assert pred.data_ptr() == self.d_in[B:].data_ptr()
+        self._start_vgg_pred()
         yield from self._d_iteration(last=False)
         if self.fresh_d:
             yield from self._d_iteration(last=False, first=False)
