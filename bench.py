@@ -53,7 +53,7 @@ def instrumented_step(ts):
     from reid_gan_amd._lib import lib
     rec = []            # (family, template, flops, bytes, event, event)
     names = ("conv2d", "conv2d_tap_mse", "conv2d_wgrad", "bgemm", "attn_fwd", "attn_bwd", "conv2d_signs",
-             "conv2d_s2_dgrad_c1fold")
+             "conv2d_s2_dgrad_c1fold", "conv2d_tap_mse_bf16")
     orig = {k: getattr(ops, k) for k in names}
 
     def timed(family, template, flops, nbytes, fn):
@@ -95,6 +95,12 @@ def instrumented_step(ts):
         timed("conv", ops.conv2d_which(x, w, y, 3, 3, 1, 1, 1, 1, bias=bias, act=1, stats=stats) + " +tap MSE",
               2.0 * y.npix * y.C * x.C * 9, nb, lambda: orig["conv2d_tap_mse"](x, w, bias, y, target, gout, gscale, stats))
 
+    def tap16(x, w, bias, y, target, gout, gscale, stats):    # ... with the target tap as stored bf16 activations
+        nb = 2.0 * (x.npix * x.C + w.numel() + 3 * y.npix * y.C)
+        timed("conv", ops.conv2d_which(x, w, y, 3, 3, 1, 1, 1, 1, bias=bias, act=1, stats=stats) + " +tap MSE",
+              2.0 * y.npix * y.C * x.C * 9, nb,
+              lambda: orig["conv2d_tap_mse_bf16"](x, w, bias, y, target, gout, gscale, stats))
+
     def wgrad(g, p, kh, kw_, sh, sw, ph, pw, slab, splitk):
         bm, bn = (64 if g.C <= 64 else 128), (64 if p.C <= 64 else 128)
         nb = 2.0 * (g.npix * g.C + p.npix * p.C) + 4.0 * splitk * kh * kw_ * p.C * g.C
@@ -118,7 +124,7 @@ def instrumented_step(ts):
               2.0 * nimg * n * (4 * d + 4 * C), lambda: orig["attn_bwd"](qkv, dqkv, dout, O, lse_ptr, gamma, dgamma, d))
 
     ops.conv2d, ops.conv2d_tap_mse, ops.conv2d_wgrad, ops.bgemm = conv, tap, wgrad, bgemm
-    ops.conv2d_signs, ops.conv2d_s2_dgrad_c1fold = conv_signs, c1fold
+    ops.conv2d_signs, ops.conv2d_s2_dgrad_c1fold, ops.conv2d_tap_mse_bf16 = conv_signs, c1fold, tap16
     ops.attn_fwd, ops.attn_bwd = attn_fwd, attn_bwd
     launch_wj, launch_cj = ops.WgradJobs.launch, ops.ConvJobs.launch      # the grouped launches of the generator
 
@@ -132,8 +138,9 @@ def instrumented_step(ts):
         timed("conv", "conv_glds_jobs_kernel<64,64,2>", self.flops, self.bytes, lambda: launch_cj(self))
     ops.WgradJobs.launch, ops.ConvJobs.launch = wj, cj
     # kernels timed one at a time: no side streams while the events are in place
-    saved = (ts.overlap_vgg, ts.overlap_gbwd, os.environ.get("RIED_SERIAL_BRANCHES"), ts.overlap_dreal)
-    ts.overlap_vgg = ts.overlap_gbwd = ts.overlap_dreal = False
+    saved = (ts.overlap_vgg, ts.overlap_gbwd, os.environ.get("RIED_SERIAL_BRANCHES"), ts.overlap_dreal,
+             ts.overlap_vgg_pred)
+    ts.overlap_vgg = ts.overlap_gbwd = ts.overlap_dreal = ts.overlap_vgg_pred = False
     os.environ["RIED_SERIAL_BRANCHES"] = "1"
     try:
         # An event pair also spans the time the GPU waits for the host to submit the launch between them, so the
@@ -149,7 +156,7 @@ def instrumented_step(ts):
         for k, v in orig.items():
             setattr(ops, k, v)
         ops.WgradJobs.launch, ops.ConvJobs.launch = launch_wj, launch_cj
-        ts.overlap_vgg, ts.overlap_gbwd, ts.overlap_dreal = saved[0], saved[1], saved[3]
+        ts.overlap_vgg, ts.overlap_gbwd, ts.overlap_dreal, ts.overlap_vgg_pred = saved[0], saved[1], saved[3], saved[4]
         if saved[2] is None:
             del os.environ["RIED_SERIAL_BRANCHES"]
         else:

@@ -171,6 +171,7 @@ class TrainStep:
         self.dpred = torch.zeros(B, 1, H, W, dtype=F32, device=device)
         self.dpred_v = torch.zeros(B, 1, H, W, dtype=F32, device=device)      # the perceptual term's share (see OVERLAP_VGG_PRED)
         self._vggp_side = None
+        self.overlap_vgg_pred = OVERLAP_VGG_PRED
         self.sc = torch.zeros(16, dtype=F32, device=device)
         self.ssim_sums = torch.zeros(B, 4, dtype=F32, device=device)
         self.gmap = torch.empty(3, B, H, W, dtype=F32, device=device)
@@ -414,7 +415,7 @@ class TrainStep:
     def _start_vgg_pred(self):
         """After the generator forward: the perceptual term on the VGG side stream (see OVERLAP_VGG_PRED)."""
         self._vggp_side = None
-        if not (OVERLAP_VGG_PRED and not self.segmented):
+        if not (self.overlap_vgg_pred and not self.segmented):
             return
         self.sc[SC_VGG:SC_VGG + 1].zero_()
         self.dpred_v.zero_()
