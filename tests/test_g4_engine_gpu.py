@@ -476,6 +476,33 @@ def test_gradient_buckets_follow_the_state_dict_order(monkeypatch):
     grad_close(a, b, "two buckets vs one", cos=0.995, ratio=0.03)
 
 
+def test_perceptual_pass_beside_the_discriminator_gives_what_it_gives_alone(monkeypatch):
+    """The perceptual term runs on a side stream beside the discriminator's first iteration.  Its kernels must not
+    care: after every step the stored image gradient equals a recomputation of the last kernel from the final buffers,
+    bit for bit (an earlier form of that kernel lost a few pixels in 8 % of the steps once other kernels ran beside
+    it), and the overlapped and the in-line step leave the same weights."""
+    from reid_gan_amd import train_step
+    monkeypatch.setattr(engine, "BN_FOLD", False)        # fixed-order reductions
+    B, H = 4, 64
+    gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
+    batches = [tuple(t.to(DEV) for t in synth_batch(B, H, seed=60 + i)) for i in range(3)]
+    assert train_step.OVERLAP_VGG_PRED
+    finals = []
+    for rep in range(16):
+        ts = TrainStep(gsd, dsd, vgg, B, H, H, lr=1e-4, use_graph=False)
+        assert ts.overlap_vgg_pred
+        ts.overlap_vgg_pred = rep != 15                  # the last run in line
+        for i in range(3):
+            ts.step(*batches[i])
+            torch.cuda.synchronize()
+            again = torch.zeros_like(ts.dpred_v)
+            ops.conv_c1_dgrad(ts.V.a0.images(0, B).g, ts.V.w0, again, scale=ts.V.in_scale, accumulate=True)
+            assert torch.equal(again, ts.dpred_v), (rep, i, int((again != ts.dpred_v).sum()))
+        finals.append(ts)
+    for other in finals[1:]:
+        weights_agree(finals[0], other, steps=3)
+
+
 def test_inference_engine_packs_its_weights_once_and_on_request():
     """The engine builds the packed weights when it is made, not at every pass: new weights take effect through
     refresh_weights() - and then the engine equals one built from them."""
