@@ -105,9 +105,9 @@ def case_g_bn_apply_fwd(ts):       # upper bound of what fusing the BatchNorm ap
     engine.ops.bn_apply_train_jobs = lambda *a, **k: None
 
 def case_sn_and_packs(ts):
-    ts.D.ctx.sn_sigmas = lambda: None
-    ts.D.ctx.pack_all = lambda: None
-    ts.D.ctx.sn_finish_wgrads = lambda: None
+    ts.D.ctx.sn_sigmas = lambda *a, **k: None
+    ts.D.ctx.pack_all = lambda *a, **k: None
+    ts.D.ctx.sn_finish_wgrads = lambda *a, **k: None
 
 cases = {k[5:]: v for k, v in globals().items() if k.startswith("case_")}
 want = sys.argv[1:] or list(cases)

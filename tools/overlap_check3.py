@@ -9,7 +9,7 @@ from reid_gan_amd.train_step import TrainStep
 from gpu_util import g_state, d_state, DEV
 
 engine.BN_FOLD = False
-B, H = 4, 64
+B, H = int(os.environ.get("B", "4")), 64
 gsd, dsd, vgg = g_state(), d_state(), synth_vgg()
 batches = [tuple(t.to(DEV) for t in synth_batch(B, H, seed=60 + i)) for i in range(4)]
 GRAPH = bool(int(os.environ.get("GRAPH", "0")))
