@@ -76,6 +76,7 @@ VGG_BF16_TARGETS = os.environ.get("RIED_VGG_BF16_TARGETS", "1") != "0"
 # that the generator-loss backward adds in.  Single-graph plans only (a side stream may not stay open across the
 # collectives of a data-parallel step).  RIED_OVERLAP_VGG_PRED=0: in line, after the discriminator's second forward.
 OVERLAP_VGG_PRED = os.environ.get("RIED_OVERLAP_VGG_PRED", "1") != "0"
+VGGP_LANE = int(os.environ.get("RIED_VGGP_LANE", str(VGG_LANE)))      # (which side stream: they map to few hardware queues)
 
 
 def _free_graphs() -> bool:
@@ -419,7 +420,7 @@ class TrainStep:
             return
         self.sc[SC_VGG:SC_VGG + 1].zero_()
         self.dpred_v.zero_()
-        s = self._vgg_side if self._vgg_side is not None else side_stream(VGG_LANE)
+        s = self._vgg_side if self._vgg_side is not None else side_stream(VGGP_LANE)
         s.wait_stream(torch.cuda.current_stream())      # the prediction, the two clears (and, in stream order, the target taps)
         with torch.cuda.stream(s):
             self._vgg_pred_pass(self.dpred_v)
